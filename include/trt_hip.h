@@ -1,0 +1,141 @@
+/*
+ * trt_hip.h -- C-ABI of libtrt_hip.so, the MI355X (gfx950) frame producer.
+ *
+ * Plain C: pointers, ints and the structs of trt.h.  No C++/torch types cross it.
+ * Each entry cites the reference interface it replaces or serves
+ * ("TRT.c:N" = TerminalRayTracer.c line N of david-andrew/TerminalRayTracer).
+ *
+ * Two layers:
+ *   1. drop-in          project_scene()            -- same symbol, same signature as TRT.c:966
+ *   2. extended/context trt_*                      -- run-time bounce limit / rays per pixel
+ *      (macros in the reference, TRT.c:54,58), device-resident framebuffers for off-screen
+ *      rendering, row-tile sharding for multi-GPU, RGB8 quantisation for the emitter.
+ *
+ * All functions returning int return TRT_OK (0) or a negative TRT_ERR_*; trt_last_error()
+ * gives the message.  A context is bound to one device and one stream and is not
+ * thread-safe; separate contexts are independent.
+ */
+#ifndef TRT_HIP_H
+#define TRT_HIP_H
+
+#include "trt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum
+{
+    TRT_OK = 0,
+    TRT_ERR_HIP = -1,         /* a HIP runtime call failed */
+    TRT_ERR_ARGUMENT = -2,    /* NULL / out-of-range argument */
+    TRT_ERR_NO_SCENE = -3,    /* render before trt_set_scene */
+    TRT_ERR_CAPACITY = -4,    /* output buffer too small, or scene too large for LDS staging */
+    TRT_ERR_NOT_INITIALISED = -5
+};
+
+/* ---- 1. drop-in ------------------------------------------------------------------------------ */
+
+/* Replaces `void project_scene(Scene *scene, Screen *screen)` (TRT.c:966; caller TRT.c:1339).
+ * Same semantics at the reference's compile-time constants BOUNCE_LIMIT=10, RAYS_PER_PIXEL=10:
+ * reads *scene (host pointers inside), overwrites screen->pixels[0 .. width*height).
+ * Lazily creates a default context on device 0.  void like the original: a HIP failure prints
+ * the error and aborts (the reference cannot fail here either). */
+void project_scene(Scene *scene, Screen *screen);
+
+/* project_scene with the two macros as run-time values (TRT.c:54, TRT.c:58).  Host in, host out. */
+int trt_render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_per_pixel);
+
+/* Default-context management for the two calls above.  trt_init is optional (device 0 otherwise). */
+int trt_init(int device);
+int trt_shutdown(void);
+
+/* Pre-upload a cubemap for the default context (what load_skybox, TRT.c:388, produced).  The
+ * default context otherwise uploads on first use and re-uploads only when the face pointers,
+ * the dimension or trt_invalidate_skybox() say the texels changed. */
+int trt_upload_skybox(const Skybox *skybox);
+int trt_invalidate_skybox(void);
+
+/* ---- 2. context API (device-resident) --------------------------------------------------------- */
+
+typedef struct trt_context trt_context;
+
+/* Rows of a W x H frame owned by one renderer, as interleaved row tiles: tiles of `tile_rows`
+ * rows, this renderer owns tiles tile_first, tile_first+tile_step, ...  The renderer's
+ * framebuffer is compact: owned rows in ascending order, `width` pixels each.
+ * Whole frame: {W, H, H, 0, 1}. */
+typedef struct
+{
+    int width;
+    int height;
+    int tile_rows;
+    int tile_first;
+    int tile_step;
+} trt_rowset;
+
+/* number of frame rows a rowset owns (0 on invalid input) */
+int trt_rowset_rows(const trt_rowset *rows);
+/* frame row of local row i, or -1 */
+int trt_rowset_frame_row(const trt_rowset *rows, int local_row);
+
+int trt_create(int device, trt_context **out);
+int trt_destroy(trt_context *ctx);
+
+/* Use an existing HIP stream (hipStream_t passed as void*; NULL = the context's own stream).
+ * PyTorch callers pass torch.cuda.current_stream().cuda_stream. */
+int trt_set_stream(trt_context *ctx, void *hip_stream);
+
+/* Upload everything of *scene except the camera: spheres, ground, lights, skybox texels.
+ * (Scene layout TRT.c:196-208.)  Synchronous; call once per scene, not per frame. */
+int trt_set_scene(trt_context *ctx, const Scene *scene);
+
+/* Render the owned rows into DEVICE memory: d_pixels[local_row*width + col] = 3 doubles
+ * (the Screen layout of TRT.c:188-193).  Asynchronous on the context's stream.
+ * camera: TRT.c:178-184, by value per frame as main() does (TRT.c:1327-1339). */
+int trt_render_device(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit,
+                      int rays_per_pixel, void *d_pixels, size_t capacity_bytes);
+
+/* (int)(c*255) per channel (TRT.c:1157-1163) on the device: 3 bytes per pixel. Asynchronous. */
+int trt_quantize_device(trt_context *ctx, const void *d_pixels, size_t num_pixels, void *d_rgb8);
+
+/* Same as trt_render_device but into HOST memory (synchronous; pinned staging inside). */
+int trt_render_host(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit,
+                    int rays_per_pixel, Vector *pixels);
+
+int trt_synchronize(trt_context *ctx);
+
+/* HIP-event durations (ms) of the most recent render-kernel launches on this context, newest
+ * last; returns how many were written (<= max).  Synchronises the stream. */
+int trt_kernel_times(trt_context *ctx, float *ms, int max);
+
+/* Work counters of the LAST rendered frame (device atomics, only when enabled; off by default
+ * so timed runs carry no atomics).  path = trace calls from the bounce loop (TRT.c:1024),
+ * shadow = trace calls from lighting (TRT.c:907, :937). */
+int trt_enable_counters(trt_context *ctx, int enable);
+int trt_read_counters(trt_context *ctx, unsigned long long *path_rays, unsigned long long *shadow_rays);
+
+/* Kernel selection: 0 = production kernel; 1 = reference-order debugging kernel (one lane per
+ * pixel, no culling).  Both are HIP; there is no CPU path. */
+int trt_set_kernel(trt_context *ctx, int which);
+
+/* Resource usage of the selected render kernel (hipFuncGetAttributes / occupancy query). */
+int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *static_lds_bytes, int *max_blocks_per_cu,
+                    int *compute_units);
+
+/* Device rounding self-test: quot[i] = a[i] / b[i], root[i] = sqrt(a[i]) computed by the same
+ * device instructions sequences the kernels use (host arrays in/out). */
+int trt_selftest_div_sqrt(trt_context *ctx, const double *a, const double *b, size_t n, double *quot, double *root);
+
+/* Single-ray probe for tests: closest hit of TRT.c:793 for n rays (host arrays): obj[n],
+ * point[3n], normal[3n], material[5n] (colour, reflectivity, specularity); lit[3n] = colour after
+ * the lighting of TRT.c:894 for hits. */
+int trt_probe_rays(trt_context *ctx, const Ray *rays, size_t n, int *obj, double *point, double *normal,
+                   double *material, double *lit);
+
+const char *trt_last_error(void);
+const char *trt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,724 @@
+// trt_capi.hip -- host side of libtrt_hip.so: contexts, uploads, launches.  C-ABI of include/trt_hip.h.
+// Compiled for gfx950 only, with -ffp-contract=off (see trt_device.hpp).
+#include "trt_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "trt_device.hpp"
+#include "trt_persistent.hpp"
+#include "trt_simple.hpp"
+
+namespace
+{
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do                                                                                                     \
+    {                                                                                                      \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(TRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kEventRing = 256;
+constexpr double kPi = 3.14159265358979323846; // TRT.c:43
+
+// TRT.c:225-228
+double triangle_wave(double t)
+{
+    double m = fmod(t, 2 * kPi);
+    return (m < kPi) ? (m / kPi) : (2 - (m / kPi));
+}
+
+template <typename T>
+struct DeviceBuffer
+{
+    T *ptr = nullptr;
+    size_t capacity = 0; // elements
+    hipError_t reserve(size_t n)
+    {
+        if (n <= capacity && ptr)
+            return hipSuccess;
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        capacity = 0;
+        hipError_t e = hipMalloc((void **)&ptr, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess)
+            capacity = std::max<size_t>(n, 1);
+        return e;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        capacity = 0;
+    }
+};
+
+} // namespace
+
+struct trt_context
+{
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int compute_units = 0;
+    int lds_limit = 0;
+
+    bool have_scene = false;
+    trt::SceneView scene{};
+    trt::CullView cull{};
+    int persistent_blocks_per_cu = 0; // occupancy of the production kernel for the current scene's LDS image
+    DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb;
+    DeviceBuffer<float> d_cull;
+    DeviceBuffer<uint32_t> d_sky;
+    DeviceBuffer<unsigned long long> d_counters;
+    DeviceBuffer<unsigned int> d_queue;
+    double *h_staging = nullptr; // pinned
+    size_t h_staging_bytes = 0;
+
+    // jitter cache key
+    int jit_spp = -1;
+    double jit_pw = 0.0, jit_ph = 0.0;
+
+    int kernel = 0; // 0 production (persistent), 1 reference-order
+    bool counters_enabled = false;
+
+    hipEvent_t ev_start[kEventRing], ev_stop[kEventRing];
+    long launches = 0;
+
+    // skybox cache key of the default context
+    const void *sky_faces[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int sky_dim = -1;
+};
+
+namespace
+{
+
+size_t scene_lds_bytes(const trt::SceneView &s)
+{
+    return sizeof(double) * ((size_t)s.num_spheres * trt::kSphereDoubles + (size_t)s.num_dir * trt::kDirLightDoubles +
+                             (size_t)s.num_point * trt::kPointLightDoubles);
+}
+
+int upload_skybox(trt_context *ctx, const Skybox *sky)
+{
+    const int dim = sky->dim;
+    if (dim <= 0)
+        return fail(TRT_ERR_ARGUMENT, "skybox dim %d", dim);
+    for (int f = 0; f < 6; f++)
+        if (!sky->colors[f])
+            return fail(TRT_ERR_ARGUMENT, "skybox face %d is NULL", f);
+    const size_t face = (size_t)dim * dim;
+    std::vector<uint32_t> packed(6 * face);
+    for (int f = 0; f < 6; f++)
+    {
+        const Color *src = sky->colors[f];
+        uint32_t *dst = packed.data() + f * face;
+        for (size_t i = 0; i < face; i++)
+            dst[i] = (uint32_t)src[i].r | ((uint32_t)src[i].g << 8) | ((uint32_t)src[i].b << 16);
+    }
+    HIP_TRY(ctx->d_sky.reserve(6 * face));
+    HIP_TRY(hipMemcpy(ctx->d_sky.ptr, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->scene.sky = ctx->d_sky.ptr;
+    ctx->scene.sky_dim = dim;
+    for (int f = 0; f < 6; f++)
+        ctx->sky_faces[f] = sky->colors[f];
+    ctx->sky_dim = dim;
+    return TRT_OK;
+}
+
+// everything of the scene except camera and skybox
+int upload_primitives(trt_context *ctx, const Scene *scene)
+{
+    const int n = scene->num_spheres, nd = scene->num_directional_lights, np = scene->num_point_lights;
+    if (n < 0 || nd < 0 || np < 0)
+        return fail(TRT_ERR_ARGUMENT, "negative primitive count");
+    if ((n && !scene->spheres) || (nd && !scene->directional_lights) || (np && !scene->point_lights))
+        return fail(TRT_ERR_ARGUMENT, "NULL primitive array with a non-zero count");
+    HIP_TRY(ctx->d_spheres.reserve((size_t)n * 9));
+    HIP_TRY(ctx->d_dir.reserve((size_t)nd * 6));
+    HIP_TRY(ctx->d_point.reserve((size_t)np * 7));
+    if (n)
+        HIP_TRY(hipMemcpy(ctx->d_spheres.ptr, scene->spheres, (size_t)n * sizeof(Sphere), hipMemcpyHostToDevice));
+    if (nd)
+        HIP_TRY(hipMemcpy(ctx->d_dir.ptr, scene->directional_lights, (size_t)nd * sizeof(DirectionalLight), hipMemcpyHostToDevice));
+    if (np)
+        HIP_TRY(hipMemcpy(ctx->d_point.ptr, scene->point_lights, (size_t)np * sizeof(PointLight), hipMemcpyHostToDevice));
+
+    // FP32 culling table {Cx,Cy,Cz,kk} of trt_filter.h (filter only, never decides a result).
+    // C = c - c0 with c0 the centre of the centres' bounding box; kk = |C|^2 - r^2, both formed in FP64
+    // and then rounded once.  Padded to kCullGroup entries with kk = +inf (never passes).
+    const int padded = (n + trt::kCullGroup - 1) / trt::kCullGroup * trt::kCullGroup;
+    std::vector<float> cull((size_t)padded * 4);
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++)
+    {
+        const double c[3] = {scene->spheres[i].center.x, scene->spheres[i].center.y, scene->spheres[i].center.z};
+        for (int j = 0; j < 3; j++)
+        {
+            lo[j] = (i == 0 || c[j] < lo[j]) ? c[j] : lo[j];
+            hi[j] = (i == 0 || c[j] > hi[j]) ? c[j] : hi[j];
+        }
+    }
+    const double c0[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+    double cn = 0.0, rm = 0.0;
+    for (int i = 0; i < n; i++)
+    {
+        const Sphere &sp = scene->spheres[i];
+        const double C[3] = {sp.center.x - c0[0], sp.center.y - c0[1], sp.center.z - c0[2]};
+        const double c2 = C[0] * C[0] + C[1] * C[1] + C[2] * C[2];
+        cull[4 * i + 0] = (float)C[0];
+        cull[4 * i + 1] = (float)C[1];
+        cull[4 * i + 2] = (float)C[2];
+        cull[4 * i + 3] = (float)(c2 - sp.radius * sp.radius);
+        cn = std::max(cn, sqrt(c2));
+        rm = std::max(rm, fabs(sp.radius));
+    }
+    for (int i = n; i < padded; i++)
+    {
+        cull[4 * i + 0] = cull[4 * i + 1] = cull[4 * i + 2] = 0.0f;
+        cull[4 * i + 3] = INFINITY;
+    }
+    HIP_TRY(ctx->d_cull.reserve(cull.size()));
+    if (padded)
+        HIP_TRY(hipMemcpy(ctx->d_cull.ptr, cull.data(), cull.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->cull.table = ctx->d_cull.ptr;
+    ctx->cull.padded = padded;
+    ctx->cull.c0x = c0[0];
+    ctx->cull.c0y = c0[1];
+    ctx->cull.c0z = c0[2];
+    ctx->cull.cn = nextafterf((float)(cn * (1.0 + 1e-6)), INFINITY); // rounded UP
+    ctx->cull.rm = nextafterf((float)(rm * (1.0 + 1e-6)), INFINITY);
+
+    trt::SceneView &v = ctx->scene;
+    v.spheres = ctx->d_spheres.ptr;
+    v.dir_lights = ctx->d_dir.ptr;
+    v.point_lights = ctx->d_point.ptr;
+    v.num_spheres = n;
+    v.num_dir = nd;
+    v.num_point = np;
+    memcpy(v.ground, &scene->ground, sizeof(Plane));
+    const size_t lds_need = std::max(scene_lds_bytes(v), trt::persistent_lds_bytes(v));
+    if (lds_need > (size_t)ctx->lds_limit)
+        return fail(TRT_ERR_CAPACITY, "scene needs %zu B of LDS staging, device offers %d", lds_need, ctx->lds_limit);
+    int blocks = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false>, trt::kPersistentBlock,
+                                                         trt::persistent_lds_bytes(v)));
+    ctx->persistent_blocks_per_cu = std::max(blocks, 1);
+    return TRT_OK;
+}
+
+int prepare_jitter(trt_context *ctx, const Camera *cam, int width, int height, int spp)
+{
+    // TRT.c:981-982, :992-993: triangle_wave(2*PI*k/spp)/2*pixel_width and triangle_wave(PI*k/spp)/2*pixel_height
+    const double pw = cam->screen_width / width, ph = cam->screen_height / height;
+    if (ctx->jit_spp == spp && ctx->jit_pw == pw && ctx->jit_ph == ph)
+        return TRT_OK;
+    std::vector<double> j(2 * (size_t)spp);
+    for (int k = 0; k < spp; k++)
+    {
+        j[k] = triangle_wave(2 * kPi * k / spp) / 2 * pw;
+        j[spp + k] = triangle_wave(kPi * k / spp) / 2 * ph;
+    }
+    HIP_TRY(ctx->d_jitter.reserve(j.size()));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still read the old table
+    HIP_TRY(hipMemcpy(ctx->d_jitter.ptr, j.data(), j.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->jit_spp = spp;
+    ctx->jit_pw = pw;
+    ctx->jit_ph = ph;
+    return TRT_OK;
+}
+
+bool rowset_valid(const trt_rowset *r)
+{
+    return r && r->width > 0 && r->height > 0 && r->tile_rows > 0 && r->tile_first >= 0 && r->tile_step > 0;
+}
+
+} // namespace
+
+extern "C" int trt_rowset_rows(const trt_rowset *r)
+{
+    if (!rowset_valid(r))
+        return 0;
+    const int tiles = (r->height + r->tile_rows - 1) / r->tile_rows;
+    long rows = 0;
+    for (int t = r->tile_first; t < tiles; t += r->tile_step)
+        rows += std::min(r->tile_rows, r->height - t * r->tile_rows);
+    return (int)rows;
+}
+
+extern "C" int trt_rowset_frame_row(const trt_rowset *r, int local_row)
+{
+    if (!rowset_valid(r) || local_row < 0 || local_row >= trt_rowset_rows(r))
+        return -1;
+    const int t = local_row / r->tile_rows;
+    return (r->tile_first + t * r->tile_step) * r->tile_rows + (local_row - t * r->tile_rows);
+}
+
+extern "C" const char *trt_last_error(void) { return g_error; }
+extern "C" const char *trt_version(void) { return "trt-mi355x 0.1 (gfx950, fp64, contraction off)"; }
+
+extern "C" int trt_create(int device, trt_context **out)
+{
+    if (!out)
+        return fail(TRT_ERR_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count)
+        return fail(TRT_ERR_ARGUMENT, "device %d out of range (%d visible)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    trt_context *ctx = new trt_context();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    ctx->compute_units = prop.multiProcessorCount;
+    ctx->lds_limit = (int)prop.sharedMemPerBlock;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    for (int i = 0; i < kEventRing; i++)
+    {
+        HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
+        HIP_TRY(hipEventCreate(&ctx->ev_stop[i]));
+    }
+    HIP_TRY(ctx->d_counters.reserve(2));
+    HIP_TRY(ctx->d_queue.reserve(64));
+    HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int)));
+    // dynamic LDS above the 64 KiB default needs the opt-in attribute
+    (void)hipFuncSetAttribute((const void *)trt::render_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::probe_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    *out = ctx;
+    return TRT_OK;
+}
+
+extern "C" int trt_destroy(trt_context *ctx)
+{
+    if (!ctx)
+        return TRT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < kEventRing; i++)
+    {
+        (void)hipEventDestroy(ctx->ev_start[i]);
+        (void)hipEventDestroy(ctx->ev_stop[i]);
+    }
+    ctx->d_spheres.release();
+    ctx->d_dir.release();
+    ctx->d_point.release();
+    ctx->d_jitter.release();
+    ctx->d_fb.release();
+    ctx->d_cull.release();
+    ctx->d_sky.release();
+    ctx->d_counters.release();
+    ctx->d_queue.release();
+    if (ctx->h_staging)
+        (void)hipHostFree(ctx->h_staging);
+    if (ctx->own_stream)
+        (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return TRT_OK;
+}
+
+extern "C" int trt_set_stream(trt_context *ctx, void *hip_stream)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return TRT_OK;
+}
+
+extern "C" int trt_set_scene(trt_context *ctx, const Scene *scene)
+{
+    if (!ctx || !scene)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->have_scene = false;
+    int rc = upload_primitives(ctx, scene);
+    if (rc)
+        return rc;
+    rc = upload_skybox(ctx, &scene->skybox);
+    if (rc)
+        return rc;
+    ctx->have_scene = true;
+    return TRT_OK;
+}
+
+extern "C" int trt_set_kernel(trt_context *ctx, int which)
+{
+    if (!ctx || which < 0 || which > 1)
+        return fail(TRT_ERR_ARGUMENT, "kernel %d", which);
+    ctx->kernel = which;
+    return TRT_OK;
+}
+
+extern "C" int trt_enable_counters(trt_context *ctx, int enable)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    ctx->counters_enabled = enable != 0;
+    return TRT_OK;
+}
+
+extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays, unsigned long long *shadow_rays)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long c[2];
+    HIP_TRY(hipMemcpy(c, ctx->d_counters.ptr, sizeof c, hipMemcpyDeviceToHost));
+    if (path_rays)
+        *path_rays = c[0];
+    if (shadow_rays)
+        *shadow_rays = c[1];
+    return TRT_OK;
+}
+
+extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit,
+                                 int rays_per_pixel, void *d_pixels, size_t capacity_bytes)
+{
+    if (!ctx || !camera || !d_pixels)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (!rowset_valid(rows))
+        return fail(TRT_ERR_ARGUMENT, "invalid rowset");
+    if (bounce_limit < 1 || rays_per_pixel < 1) // bounce_limit 0 divides 0 by 0 in the reference (TRT.c:1061)
+        return fail(TRT_ERR_ARGUMENT, "bounce_limit %d / rays_per_pixel %d", bounce_limit, rays_per_pixel);
+    if (!ctx->have_scene)
+        return fail(TRT_ERR_NO_SCENE, "trt_set_scene has not been called");
+    const int local_rows = trt_rowset_rows(rows);
+    const size_t need = (size_t)local_rows * rows->width * sizeof(Vector);
+    if (capacity_bytes < need)
+        return fail(TRT_ERR_CAPACITY, "framebuffer needs %zu B, %zu given", need, capacity_bytes);
+    if (local_rows == 0)
+        return TRT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = prepare_jitter(ctx, camera, rows->width, rows->height, rays_per_pixel);
+    if (rc)
+        return rc;
+
+    trt::FrameView f{};
+    memcpy(f.cam, camera, sizeof(Camera));
+    f.jitter = ctx->d_jitter.ptr;
+    f.out = (double *)d_pixels;
+    f.counters = ctx->counters_enabled ? ctx->d_counters.ptr : nullptr;
+    f.queue = ctx->d_queue.ptr;
+    f.width = rows->width;
+    f.height = rows->height;
+    f.tile_rows = rows->tile_rows;
+    f.tile_first = rows->tile_first;
+    f.tile_step = rows->tile_step;
+    f.local_rows = local_rows;
+    f.bounce_limit = bounce_limit;
+    f.spp = rays_per_pixel;
+
+    const long pixels = (long)local_rows * rows->width;
+    const size_t lds = scene_lds_bytes(ctx->scene);
+    if (ctx->counters_enabled)
+        HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    const int slot = (int)(ctx->launches % kEventRing);
+    if (ctx->kernel == 1)
+    {
+        const int block = 256;
+        const unsigned grid = (unsigned)((pixels + block - 1) / block);
+        HIP_TRY(hipEventRecord(ctx->ev_start[slot], ctx->stream));
+        hipLaunchKernelGGL(trt::render_simple_kernel, dim3(grid), dim3(block), lds, ctx->stream, ctx->scene, f);
+        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
+    }
+    else
+    {
+        HIP_TRY(hipMemsetAsync(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int), ctx->stream));
+        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units, ctx->persistent_blocks_per_cu, pixels);
+        const size_t plds = trt::persistent_lds_bytes(ctx->scene);
+        HIP_TRY(hipEventRecord(ctx->ev_start[slot], ctx->stream));
+        if (ctx->counters_enabled)
+            hipLaunchKernelGGL(trt::render_persistent_kernel<true>, dim3(pl.grid), dim3(pl.block), plds, ctx->stream, ctx->scene,
+                               ctx->cull, f);
+        else
+            hipLaunchKernelGGL(trt::render_persistent_kernel<false>, dim3(pl.grid), dim3(pl.block), plds, ctx->stream, ctx->scene,
+                               ctx->cull, f);
+        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    ctx->launches++;
+    return TRT_OK;
+}
+
+extern "C" int trt_quantize_device(trt_context *ctx, const void *d_pixels, size_t num_pixels, void *d_rgb8)
+{
+    if (!ctx || !d_pixels || !d_rgb8)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (num_pixels == 0)
+        return TRT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const long n = (long)num_pixels * 3;
+    hipLaunchKernelGGL(trt::quantize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)d_pixels,
+                       n, (unsigned char *)d_rgb8);
+    HIP_TRY(hipGetLastError());
+    return TRT_OK;
+}
+
+extern "C" int trt_synchronize(trt_context *ctx)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return TRT_OK;
+}
+
+extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit,
+                               int rays_per_pixel, Vector *pixels)
+{
+    if (!ctx || !pixels)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (!rowset_valid(rows))
+        return fail(TRT_ERR_ARGUMENT, "invalid rowset");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t count = (size_t)trt_rowset_rows(rows) * rows->width;
+    const size_t bytes = count * sizeof(Vector);
+    HIP_TRY(ctx->d_fb.reserve(count * 3));
+    if (ctx->h_staging_bytes < bytes)
+    {
+        if (ctx->h_staging)
+            (void)hipHostFree(ctx->h_staging);
+        ctx->h_staging = nullptr;
+        ctx->h_staging_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_staging, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+        ctx->h_staging_bytes = std::max<size_t>(bytes, 1);
+    }
+    int rc = trt_render_device(ctx, camera, rows, bounce_limit, rays_per_pixel, ctx->d_fb.ptr, bytes);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_staging, ctx->d_fb.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(pixels, ctx->h_staging, bytes);
+    return TRT_OK;
+}
+
+extern "C" int trt_kernel_times(trt_context *ctx, float *ms, int max)
+{
+    if (!ctx || !ms || max < 0)
+        return fail(TRT_ERR_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const long have = std::min<long>(ctx->launches, kEventRing);
+    const long n = std::min<long>(have, max);
+    for (long i = 0; i < n; i++)
+    {
+        const long launch = ctx->launches - n + i;
+        const int slot = (int)(launch % kEventRing);
+        HIP_TRY(hipEventElapsedTime(&ms[i], ctx->ev_start[slot], ctx->ev_stop[slot]));
+    }
+    return (int)n;
+}
+
+extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *static_lds_bytes, int *max_blocks_per_cu,
+                               int *compute_units)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel : (const void *)trt::render_persistent_kernel<false>;
+    hipFuncAttributes attr;
+    HIP_TRY(hipFuncGetAttributes(&attr, fn));
+    if (vgprs)
+        *vgprs = attr.numRegs;
+    if (sgprs)
+        *sgprs = 0; // not reported by hipFuncGetAttributes; see profiles/*resource_usage*.txt
+    if (static_lds_bytes)
+        *static_lds_bytes = (int)attr.sharedSizeBytes;
+    if (max_blocks_per_cu)
+    {
+        int blocks = 0;
+        const size_t lds = ctx->have_scene ? (ctx->kernel == 1 ? scene_lds_bytes(ctx->scene) : trt::persistent_lds_bytes(ctx->scene)) : 0;
+        if (ctx->kernel == 1)
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_simple_kernel, 256, lds));
+        else
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false>, trt::kPersistentBlock, lds));
+        *max_blocks_per_cu = blocks;
+    }
+    if (compute_units)
+        *compute_units = ctx->compute_units;
+    return TRT_OK;
+}
+
+extern "C" int trt_selftest_div_sqrt(trt_context *ctx, const double *a, const double *b, size_t n, double *quot, double *root)
+{
+    if (!ctx || !a || !b || !quot || !root)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (n == 0)
+        return TRT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceBuffer<double> buf;
+    HIP_TRY(buf.reserve(4 * n));
+    double *da = buf.ptr, *db = buf.ptr + n, *dq = buf.ptr + 2 * n, *dr = buf.ptr + 3 * n;
+    HIP_TRY(hipMemcpy(da, a, n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(trt::div_sqrt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, da, db, (long)n, dq, dr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(quot, dq, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(root, dr, n * sizeof(double), hipMemcpyDeviceToHost));
+    buf.release();
+    return TRT_OK;
+}
+
+extern "C" int trt_probe_rays(trt_context *ctx, const Ray *rays, size_t n, int *obj, double *point, double *normal,
+                              double *material, double *lit)
+{
+    if (!ctx || !rays || !obj || !point || !normal || !material || !lit)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (!ctx->have_scene)
+        return fail(TRT_ERR_NO_SCENE, "trt_set_scene has not been called");
+    if (n == 0)
+        return TRT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceBuffer<double> buf;
+    DeviceBuffer<int> dobj;
+    HIP_TRY(buf.reserve(n * (6 + 3 + 3 + 5 + 3)));
+    HIP_TRY(dobj.reserve(n));
+    double *dr = buf.ptr, *dp = dr + 6 * n, *dn = dp + 3 * n, *dm = dn + 3 * n, *dl = dm + 5 * n;
+    HIP_TRY(hipMemcpy(dr, rays, n * sizeof(Ray), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(trt::probe_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), scene_lds_bytes(ctx->scene), ctx->stream,
+                       ctx->scene, dr, (long)n, dobj.ptr, dp, dn, dm, dl);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(obj, dobj.ptr, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(point, dp, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(normal, dn, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(material, dm, 5 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lit, dl, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    buf.release();
+    dobj.release();
+    return TRT_OK;
+}
+
+// ---- default context: the drop-in layer ---------------------------------------------------------------------
+
+namespace
+{
+trt_context *g_default = nullptr;
+int g_default_device = 0;
+
+int default_context(trt_context **out)
+{
+    if (!g_default)
+    {
+        int rc = trt_create(g_default_device, &g_default);
+        if (rc)
+            return rc;
+    }
+    *out = g_default;
+    return TRT_OK;
+}
+} // namespace
+
+extern "C" int trt_init(int device)
+{
+    if (g_default && g_default->device != device)
+    {
+        trt_destroy(g_default);
+        g_default = nullptr;
+    }
+    g_default_device = device;
+    trt_context *ctx;
+    return default_context(&ctx);
+}
+
+extern "C" int trt_shutdown(void)
+{
+    int rc = trt_destroy(g_default);
+    g_default = nullptr;
+    return rc;
+}
+
+extern "C" int trt_upload_skybox(const Skybox *skybox)
+{
+    if (!skybox)
+        return fail(TRT_ERR_ARGUMENT, "skybox is NULL");
+    trt_context *ctx;
+    int rc = default_context(&ctx);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return upload_skybox(ctx, skybox);
+}
+
+extern "C" int trt_invalidate_skybox(void)
+{
+    if (g_default)
+        g_default->sky_dim = -1;
+    return TRT_OK;
+}
+
+extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_per_pixel)
+{
+    if (!scene || !screen || !screen->pixels)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (screen->width <= 0 || screen->height <= 0)
+        return fail(TRT_ERR_ARGUMENT, "screen %d x %d", screen->width, screen->height);
+    trt_context *ctx;
+    int rc = default_context(&ctx);
+    if (rc)
+        return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // the caller owns the scene and may have edited it since the last frame (main() rewrites the camera
+    // every frame, TRT.c:1327-1336): primitives are a few KB and are re-sent; the 6*dim*dim texels only
+    // when the face pointers or the dimension changed
+    ctx->have_scene = false;
+    rc = upload_primitives(ctx, scene);
+    if (rc)
+        return rc;
+    bool same_sky = ctx->sky_dim == scene->skybox.dim;
+    for (int f = 0; f < 6 && same_sky; f++)
+        same_sky = ctx->sky_faces[f] == scene->skybox.colors[f];
+    if (!same_sky)
+    {
+        rc = upload_skybox(ctx, &scene->skybox);
+        if (rc)
+            return rc;
+    }
+    ctx->have_scene = true;
+    const trt_rowset whole = {screen->width, screen->height, screen->height, 0, 1};
+    return trt_render_host(ctx, &scene->camera, &whole, bounce_limit, rays_per_pixel, screen->pixels);
+}
+
+extern "C" void project_scene(Scene *scene, Screen *screen)
+{
+    const int rc = trt_render_frame(scene, screen, TRT_REF_BOUNCE_LIMIT, TRT_REF_RAYS_PER_PIXEL);
+    if (rc != TRT_OK)
+    {
+        fprintf(stderr, "project_scene (libtrt_hip): %s\n", trt_last_error());
+        abort();
+    }
+}

@@ -1,0 +1,239 @@
+// trt_device.hpp -- device-side leaf math and scene views for the gfx950 frame producer.
+//
+// Every function here evaluates in IEEE binary64 in the SAME operation order as the reference
+// (citations "TRT.c:N" = TerminalRayTracer.c line N).  The translation unit is compiled with
+// -ffp-contract=off, so a*b+c is two roundings exactly as on the reference's x86-64 build;
+// the only fused operations are the explicit __builtin_fmaf calls in the FP32 culling filter,
+// which never decides a result (it only selects which spheres get the exact FP64 test).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace trt
+{
+
+struct d3
+{
+    double x, y, z;
+};
+
+#define TRT_DEV __device__ __forceinline__
+
+TRT_DEV d3 make3(double x, double y, double z) { return d3{x, y, z}; }
+TRT_DEV d3 load3(const double *p) { return d3{p[0], p[1], p[2]}; }
+TRT_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // TRT.c:461 ((xx+yy)+zz)
+TRT_DEV d3 sub(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+TRT_DEV d3 add(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+TRT_DEV d3 mulc(d3 a, d3 b) { return d3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+TRT_DEV d3 scale(d3 a, double s) { return d3{a.x * s, a.y * s, a.z * s}; }
+
+// TRT.c:439-450: sqrt of the squared length, then THREE divisions, only when length > 1e-4
+TRT_DEV d3 unit(d3 a)
+{
+    double len = __builtin_sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    if (len > 0.0001)
+    {
+        a.x /= len;
+        a.y /= len;
+        a.z /= len;
+    }
+    return a;
+}
+
+// TRT.c:523-530 (NaN passes through, as in the reference)
+TRT_DEV double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// TRT.c:627-633: v - ((2.0*dot)*n)
+TRT_DEV d3 reflect(d3 v, d3 n)
+{
+    double d = dot(v, n);
+    return d3{v.x - 2.0 * d * n.x, v.y - 2.0 * d * n.y, v.z - 2.0 * d * n.z};
+}
+
+// (int)x as the reference's x86-64 build computes it (cvttsd2si): truncation, and the
+// "integer indefinite" 0x80000000 for NaN / out-of-range (gfx950's v_cvt_i32_f64 saturates instead).
+TRT_DEV int d2i(double x)
+{
+    return (x > -2147483649.0 && x < 2147483648.0) ? (int)x : (int)0x80000000;
+}
+
+// fmin(x, 1.0) of TRT.c:911/945 (NaN -> 1.0)
+TRT_DEV double min1(double x) { return __builtin_fmin(x, 1.0); }
+
+// ---- scene views ---------------------------------------------------------------------------------
+// Spheres/lights are the reference's AoS records viewed as doubles:
+//   Sphere (TRT.c:161)  9 doubles: cx cy cz r | colour xyz | reflectivity | specularity
+//   DirectionalLight (TRT.c:146) 6: dir xyz | colour xyz
+//   PointLight (TRT.c:153) 7: pos xyz | colour xyz | intensity
+//   Plane (TRT.c:169) 16: point | normal | even{colour,refl,spec} | odd{...}
+constexpr int kSphereDoubles = 9;
+constexpr int kDirLightDoubles = 6;
+constexpr int kPointLightDoubles = 7;
+
+struct SceneView
+{
+    const double *spheres; // global, AoS
+    const double *dir_lights;
+    const double *point_lights;
+    const uint32_t *sky; // 6 faces x dim x dim texels, 0x00BBGGRR
+    int num_spheres;
+    int num_dir;
+    int num_point;
+    int sky_dim;
+    double ground[16];
+};
+
+struct FrameView
+{
+    double cam[15];       // Camera (TRT.c:178): basis x,y,z | origin | screen_distance, screen_width, screen_height
+    const double *jitter; // 2*spp doubles: x offsets then y offsets, already scaled by the pixel size (TRT.c:992-993)
+    double *out;          // compact framebuffer of the owned rows
+    unsigned long long *counters; // [path, shadow] or nullptr
+    unsigned int *queue;  // work-queue head for the persistent kernel
+    int width, height;
+    int tile_rows, tile_first, tile_step;
+    int local_rows;
+    int bounce_limit, spp;
+};
+
+TRT_DEV int frame_row_of(const FrameView &f, int local_row)
+{
+    int t = local_row / f.tile_rows; // tiles before the last are always full
+    return (f.tile_first + t * f.tile_step) * f.tile_rows + (local_row - t * f.tile_rows);
+}
+
+// ---- exact primitive tests --------------------------------------------------------------------------
+// TRT.c:638-672.  a = d.d is passed in (same value for every sphere of a ray).
+TRT_DEV bool hit_sphere(d3 o, d3 d, double a, d3 c, double r, d3 &p)
+{
+    d3 oc = sub(o, c);
+    double b = 2.0 * dot(oc, d);
+    double cc = dot(oc, oc) - r * r;
+    double disc = b * b - 4.0 * a * cc;
+    if (disc < 0.0)
+        return false;
+    double t0 = (-b - __builtin_sqrt(disc)) / (2.0 * a);
+    if (!(t0 > 0.0))
+        return false;
+    p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
+    return true;
+}
+
+// TRT.c:677-695
+TRT_DEV bool hit_plane(d3 o, d3 d, d3 gp, d3 gn, d3 &p)
+{
+    double denom = dot(d, gn);
+    if (!(__builtin_fabs(denom) > 0.00001))
+        return false;
+    double t = dot(sub(gp, o), gn) / denom;
+    if (!(t > 0.00001))
+        return false;
+    p = d3{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};
+    return true;
+}
+
+// squared distance from the ray origin to a (rounded) hit point, TRT.c:810-815 / 834-839
+TRT_DEV double dist2(d3 o, d3 p)
+{
+    d3 b = sub(o, p);
+    return dot(b, b);
+}
+
+// TRT.c:871-874: p + unit(o - p)*1e-6
+TRT_DEV d3 nudge(d3 o, d3 p) { return add(p, scale(unit(sub(o, p)), 0.000001)); }
+
+// TRT.c:850: checker parity of a ground hit
+TRT_DEV int checker_odd(d3 p) { return d2i(__builtin_floor(p.x) + __builtin_floor(p.z)) & 1; }
+
+// ---- skybox, TRT.c:700-789 -----------------------------------------------------------------------------
+// The reference evaluates everything through dot products with the axis table; multiplying by
+// +-1/0 and adding zeros is kept (it can turn -0.0 into +0.0, and NaN/inf propagate the same way).
+TRT_DEV d3 cube_axis(int f)
+{
+    double s = (f & 1) ? -1.0 : 1.0;
+    int a = f >> 1;
+    return d3{a == 0 ? s : 0.0, a == 1 ? s : 0.0, a == 2 ? s : 0.0};
+}
+
+TRT_DEV uint32_t sky_texel(const uint32_t *sky, int dim, d3 direction)
+{
+    d3 dir = unit(direction);
+    int face = -1;
+    double best = -1.0;
+#pragma unroll
+    for (int f = 0; f < 6; f++)
+    {
+        double t = dot(dir, cube_axis(f));
+        if (t > best)
+        {
+            best = t;
+            face = f;
+        }
+    }
+    if (face < 0) // NaN direction: the reference indexes face -1 (undefined); defined here as face 0
+        face = 0;
+    d3 ax = cube_axis(face);
+    d3 touching = mulc(dir, ax);
+    double scale_by = touching.x + touching.y + touching.z;
+    dir = scale(dir, 1.0 / scale_by);
+    double along = dot(dir, ax);
+    d3 in_plane = scale(sub(dir, scale(ax, along)), 0.5);
+    double u = dot(in_plane, cube_axis((face + 2) % 6));
+    double v = dot(in_plane, cube_axis((face + 4) % 6));
+    if (face & 1)
+        u *= -1.0;
+    if (face < 2)
+    {
+        double t = u;
+        u = v;
+        v = -t;
+    }
+    else if (face < 4)
+    {
+        double t = u;
+        u = -v;
+        v = t;
+    }
+    else if (face == 4)
+    {
+        u *= -1.0;
+        v *= -1.0;
+    }
+    u = clampd(u, -0.5, 0.5);
+    v = clampd(v, -0.5, 0.5);
+    int ui = d2i((u + 0.5) * dim);
+    int vi = d2i((v + 0.5) * dim);
+    long idx = (long)ui + (long)vi * dim; // same linear index as TRT.c:788 (ui == dim runs into the next row)
+    long last = (long)dim * dim - 1;
+    if (idx > last) // reference reads past the face here (undefined); defined as the last texel
+        idx = last;
+    if (idx < 0)
+        idx = 0;
+    return sky[(long)face * dim * dim + idx];
+}
+
+TRT_DEV d3 texel_color(uint32_t t) // TRT.c:866: byte / 255.0
+{
+    return d3{(double)(t & 0xFF) / 255.0, (double)((t >> 8) & 0xFF) / 255.0, (double)((t >> 16) & 0xFF) / 255.0};
+}
+
+// ---- primary rays, TRT.c:981-1011 -------------------------------------------------------------------------
+TRT_DEV d3 primary_direction(const FrameView &f, int row, int column, int k)
+{
+    const double sw = f.cam[13], sh = f.cam[14], sd = f.cam[12];
+    double sx = (((double)column / (double)f.width) * sw - sw / 2.0);
+    double sy = -(((double)row / (double)f.height) * sh - sh / 2.0);
+    double sz = -sd;
+    sx += f.jitter[k];
+    sy += f.jitter[f.spp + k];
+    d3 bx = load3(f.cam + 0), by = load3(f.cam + 3), bz = load3(f.cam + 6), eye = load3(f.cam + 9);
+    d3 dir = d3{0.0, 0.0, 0.0};
+    dir = add(dir, scale(bx, sx));
+    dir = add(dir, scale(by, sy));
+    dir = add(dir, scale(bz, sz));
+    dir = sub(dir, eye); // sic, TRT.c:1005
+    return unit(dir);
+}
+
+} // namespace trt

@@ -1,0 +1,216 @@
+"""ctypes binding of libtrt_hip.so (C-ABI of include/trt_hip.h).
+
+This is the only compute path of the package: there is no CPU or PyTorch fallback.  If the
+HIP library is missing the import of `lib()` raises; if no GPU is present every compute call
+fails with TRT_ERR_HIP.  PyTorch is used by callers only for device memory / streams /
+torch.distributed; raw device pointers and the stream handle cross this boundary as integers.
+"""
+import ctypes as C
+import functools
+import os
+
+import numpy as np
+
+from . import layout as L
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrt_hip.so")
+
+TRT_OK = 0
+ERRORS = {-1: "TRT_ERR_HIP", -2: "TRT_ERR_ARGUMENT", -3: "TRT_ERR_NO_SCENE", -4: "TRT_ERR_CAPACITY",
+          -5: "TRT_ERR_NOT_INITIALISED"}
+
+
+class TrtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{ERRORS.get(code, code)}: {message}")
+        self.code = code
+
+
+class RowSet(C.Structure):
+    """trt_rowset: interleaved row tiles owned by one renderer (include/trt_hip.h)."""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("tile_rows", C.c_int), ("tile_first", C.c_int),
+                ("tile_step", C.c_int)]
+
+    @staticmethod
+    def whole(width, height):
+        return RowSet(width, height, height, 0, 1)
+
+    @staticmethod
+    def shard(width, height, rank, world, tile_rows=8):
+        return RowSet(width, height, tile_rows, rank, world)
+
+
+# every symbol include/trt_hip.h declares: (restype, argtypes)
+_VP, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
+SYMBOLS = {
+    "project_scene": (None, [C.POINTER(L.Scene), C.POINTER(L.Screen)]),
+    "trt_render_frame": (_I, [C.POINTER(L.Scene), C.POINTER(L.Screen), _I, _I]),
+    "trt_init": (_I, [_I]),
+    "trt_shutdown": (_I, []),
+    "trt_upload_skybox": (_I, [C.POINTER(L.Skybox)]),
+    "trt_invalidate_skybox": (_I, []),
+    "trt_rowset_rows": (_I, [C.POINTER(RowSet)]),
+    "trt_rowset_frame_row": (_I, [C.POINTER(RowSet), _I]),
+    "trt_create": (_I, [_I, C.POINTER(_VP)]),
+    "trt_destroy": (_I, [_VP]),
+    "trt_set_stream": (_I, [_VP, _VP]),
+    "trt_set_scene": (_I, [_VP, C.POINTER(L.Scene)]),
+    "trt_render_device": (_I, [_VP, C.POINTER(L.Camera), C.POINTER(RowSet), _I, _I, _VP, _SZ]),
+    "trt_quantize_device": (_I, [_VP, _VP, _SZ, _VP]),
+    "trt_render_host": (_I, [_VP, C.POINTER(L.Camera), C.POINTER(RowSet), _I, _I, _VP]),
+    "trt_synchronize": (_I, [_VP]),
+    "trt_kernel_times": (_I, [_VP, C.POINTER(C.c_float), _I]),
+    "trt_enable_counters": (_I, [_VP, _I]),
+    "trt_read_counters": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "trt_set_kernel": (_I, [_VP, _I]),
+    "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
+    "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
+    "trt_probe_rays": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
+    "trt_last_error": (C.c_char_p, []),
+    "trt_version": (C.c_char_p, []),
+}
+
+
+@functools.lru_cache(maxsize=None)
+def lib():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make lib` (hipcc --offload-arch=gfx950). "
+                          "There is no fallback path.")
+    # Load order matters when PyTorch shares the process: torch bundles its own libamdhip64/libhsa-runtime64,
+    # and a process must initialise only ONE HIP runtime.  Importing torch first (when it is installed) makes
+    # libtrt_hip.so's libamdhip64.so dependency resolve to the copy torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    dll = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(dll, name)  # AttributeError here = the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    return dll
+
+
+def _check(code):
+    if code != TRT_OK:
+        raise TrtError(code, lib().trt_last_error().decode())
+
+
+def camera_struct(camera_array):
+    cam = L.Camera()
+    a = np.ascontiguousarray(camera_array, dtype=np.float64).reshape(15)
+    C.memmove(C.byref(cam), a.ctypes.data, 120)
+    return cam
+
+
+class Context:
+    """One renderer on one GPU (trt_context)."""
+
+    PRODUCTION, REFERENCE_ORDER = 0, 1
+
+    def __init__(self, device=0):
+        self._h = _VP()
+        _check(lib().trt_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().trt_destroy(self._h)
+            self._h = _VP()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        _check(lib().trt_set_stream(self._h, _VP(stream_handle or 0)))
+
+    def set_scene(self, scene_data):
+        scene = scene_data.as_scene()
+        _check(lib().trt_set_scene(self._h, C.byref(scene)))
+
+    def set_kernel(self, which):
+        _check(lib().trt_set_kernel(self._h, which))
+
+    def render_device(self, camera_array, rows, bounce_limit, rays_per_pixel, device_ptr, capacity_bytes):
+        cam = camera_struct(camera_array)
+        _check(lib().trt_render_device(self._h, C.byref(cam), C.byref(rows), bounce_limit, rays_per_pixel,
+                                       _VP(device_ptr), capacity_bytes))
+
+    def quantize_device(self, device_ptr, num_pixels, rgb_ptr):
+        _check(lib().trt_quantize_device(self._h, _VP(device_ptr), num_pixels, _VP(rgb_ptr)))
+
+    def render_host(self, camera_array, rows, bounce_limit, rays_per_pixel):
+        n = lib().trt_rowset_rows(C.byref(rows))
+        out = np.zeros((n, rows.width, 3), dtype=np.float64)
+        cam = camera_struct(camera_array)
+        _check(lib().trt_render_host(self._h, C.byref(cam), C.byref(rows), bounce_limit, rays_per_pixel,
+                                     out.ctypes.data))
+        return out
+
+    def synchronize(self):
+        _check(lib().trt_synchronize(self._h))
+
+    def kernel_times(self, max_count=256):
+        buf = (C.c_float * max_count)()
+        n = lib().trt_kernel_times(self._h, buf, max_count)
+        if n < 0:
+            _check(n)
+        return [buf[i] for i in range(n)]
+
+    def enable_counters(self, on=True):
+        _check(lib().trt_enable_counters(self._h, 1 if on else 0))
+
+    def read_counters(self):
+        p, s = C.c_ulonglong(), C.c_ulonglong()
+        _check(lib().trt_read_counters(self._h, C.byref(p), C.byref(s)))
+        return p.value, s.value
+
+    def kernel_info(self):
+        v = [_I() for _ in range(5)]
+        _check(lib().trt_kernel_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("vgprs", "sgprs", "static_lds_bytes", "max_blocks_per_cu", "compute_units"),
+                        [x.value for x in v]))
+
+    def selftest_div_sqrt(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        q, r = np.empty_like(a), np.empty_like(a)
+        _check(lib().trt_selftest_div_sqrt(self._h, a.ctypes.data, b.ctypes.data, a.size, q.ctypes.data, r.ctypes.data))
+        return q, r
+
+    def probe_rays(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = rays.shape[0]
+        obj = np.zeros(n, dtype=np.int32)
+        point, normal, material, lit = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 5)), np.zeros((n, 3))
+        _check(lib().trt_probe_rays(self._h, rays.ctypes.data, n, obj.ctypes.data, point.ctypes.data,
+                                    normal.ctypes.data, material.ctypes.data, lit.ctypes.data))
+        return obj, point, normal, material, lit
+
+
+def render_frame(scene_data, width, height, bounce_limit=10, rays_per_pixel=10):
+    """Host-in/host-out frame through the extended entry trt_render_frame (default context)."""
+    from .scenes import new_screen
+    scene = scene_data.as_scene()
+    screen, pixels = new_screen(width, height)
+    _check(lib().trt_render_frame(C.byref(scene), C.byref(screen), bounce_limit, rays_per_pixel))
+    return pixels
+
+
+def project_scene(scene_data, width, height):
+    """The drop-in symbol itself: void project_scene(Scene*, Screen*) at B=10, spp=10 (TRT.c:966)."""
+    from .scenes import new_screen
+    scene = scene_data.as_scene()
+    screen, pixels = new_screen(width, height)
+    lib().project_scene(C.byref(scene), C.byref(screen))
+    return pixels

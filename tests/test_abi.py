@@ -1,0 +1,54 @@
+"""No-GPU checks of the drop-in boundary: libtrt_hip.so loads, exports every symbol that
+include/trt_hip.h declares, and its pure-host helpers behave.  No compute call is made."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import support as T
+from terminalraytracer_amd import hip
+
+
+def _declared_symbols():
+    text = open(os.path.join(T.ROOT, "include", "trt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(project_scene|trt_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    dll = hip.lib()
+    declared = _declared_symbols()
+    assert "project_scene" in declared and len(declared) >= 20
+    for name in declared:
+        assert hasattr(dll, name), f"{name} declared in include/trt_hip.h but not exported"
+    assert set(declared) == set(hip.SYMBOLS), set(declared) ^ set(hip.SYMBOLS)
+
+
+def test_version_and_error_strings():
+    assert b"gfx950" in hip.lib().trt_version()
+    assert isinstance(hip.lib().trt_last_error(), bytes)
+
+
+@pytest.mark.parametrize("w,h,tile,world", [(1920, 1080, 8, 8), (3840, 2160, 8, 8), (67, 13, 4, 3), (5, 1, 8, 2),
+                                             (16, 9, 1, 4), (160, 48, 48, 1)])
+def test_rowsets_partition_the_frame(w, h, tile, world):
+    lib = hip.lib()
+    seen = []
+    for rank in range(world):
+        rs = hip.RowSet.shard(w, h, rank, world, tile)
+        n = lib.trt_rowset_rows(C.byref(rs))
+        rows = [lib.trt_rowset_frame_row(C.byref(rs), i) for i in range(n)]
+        assert rows == sorted(rows) and all(0 <= r < h for r in rows)
+        assert lib.trt_rowset_frame_row(C.byref(rs), n) == -1
+        seen += rows
+    assert sorted(seen) == list(range(h))  # every row exactly once
+
+
+def test_rowset_rejects_nonsense():
+    lib = hip.lib()
+    for bad in (hip.RowSet(0, 10, 1, 0, 1), hip.RowSet(10, 10, 0, 0, 1), hip.RowSet(10, 10, 1, -1, 1),
+                hip.RowSet(10, 10, 1, 0, 0)):
+        assert lib.trt_rowset_rows(C.byref(bad)) == 0
+    assert lib.trt_rowset_rows(None) == 0

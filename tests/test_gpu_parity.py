@@ -1,0 +1,176 @@
+"""GPU parity: the HIP frame producer (through the C-ABI of include/trt_hip.h) against
+ (a) golden vectors taken from the genuine reference (tests/golden), and
+ (b) the CPU oracle on the same inputs.
+Bit-exact: the double framebuffer must be identical (which implies the 1e-5 tolerance of the
+north star and the exact (int)(c*255) colour indices)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import support as T
+from terminalraytracer_amd import hip
+from terminalraytracer_amd import scenes as S
+
+pytestmark = pytest.mark.gpu
+
+SMALL = T.golden_cases(("small", "medium"))
+LARGE = T.golden_cases(("large",))
+KERNELS = [hip.Context.PRODUCTION, hip.Context.REFERENCE_ORDER]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def render(ctx, scene, w, h, b, s, kernel=hip.Context.PRODUCTION, rows=None):
+    ctx.set_kernel(kernel)
+    ctx.set_scene(scene)
+    return ctx.render_host(scene.camera, rows or hip.RowSet.whole(w, h), b, s)
+
+
+def test_device_division_and_sqrt_are_correctly_rounded(ctx):
+    rng = np.random.default_rng(1)
+    n = 1 << 20
+    a = rng.uniform(0.0, 1.0, n) * 10.0 ** rng.uniform(-30, 30, n)
+    b = (rng.uniform(0.5, 1.0, n) * 10.0 ** rng.uniform(-30, 30, n)) * rng.choice([-1.0, 1.0], n)
+    a[:8] = [0.0, 1.0, 2.0, 1e-308, 1e308, 3.0, 0.1, 4.9e-324]
+    b[:8] = [1.0, 3.0, 1e-300, 7.0, 1e-10, 0.0, 0.3, 2.0]
+    q, r = ctx.selftest_div_sqrt(a, b)
+    wq, wr = np.empty_like(a), np.empty_like(a)
+    with np.errstate(all="ignore"):
+        T.oracle().trt_oracle_div_sqrt(a.ctypes.data, b.ctypes.data, n, wq.ctypes.data, wr.ctypes.data)
+    assert np.array_equal(bits(q), bits(wq)), int((bits(q) != bits(wq)).sum())
+    assert np.array_equal(bits(r), bits(wr)), int((bits(r) != bits(wr)).sum())
+
+
+def test_single_rays_match_reference_vectors(ctx):
+    d = np.load(T.GOLDEN + "/rays.npz")
+    scene = S.SceneData.from_arrays(d, T.sky("uv_checker"), prefix="scene/")
+    ctx.set_scene(scene)
+    obj, point, normal, material, lit = ctx.probe_rays(d["rays"])
+    assert np.array_equal(obj, d["obj"])
+    assert np.array_equal(bits(point), bits(d["point"]))
+    assert np.array_equal(bits(normal), bits(d["normal"]))
+    assert np.array_equal(bits(material), bits(d["material"]))
+    hit = obj != 0
+    assert np.array_equal(bits(lit[hit]), bits(d["lit"][hit]))
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=["production", "reference_order"])
+@pytest.mark.parametrize("case", SMALL, ids=[c["name"] for c in SMALL])
+def test_frame_matches_reference_golden(ctx, case, kernel):
+    scene = T.golden_scene(case)
+    px = render(ctx, scene, case["width"], case["height"], case["bounce_limit"], case["rays_per_pixel"], kernel)
+    fb = T.golden_fb(case)
+    if fb is not None and not np.array_equal(bits(px), bits(fb)):
+        bad = np.argwhere((bits(px) != bits(fb)).any(axis=2))
+        pytest.fail(f"{len(bad)} pixels differ, first {bad[:5].tolist()}")
+    assert T.fnv(px) == case["fb_fnv"]
+    assert T.fnv(T.oracle_rgb8(px)) == case["rgb8_fnv"]
+
+
+@pytest.mark.parametrize("case", LARGE, ids=[c["name"] for c in LARGE])
+def test_full_hd_frame_matches_reference_golden(ctx, case):
+    scene = T.golden_scene(case)
+    px = render(ctx, scene, case["width"], case["height"], case["bounce_limit"], case["rays_per_pixel"])
+    assert T.fnv(px) == case["fb_fnv"]
+
+
+def test_drop_in_project_scene_symbol():
+    """void project_scene(Scene*, Screen*) itself, at the reference's B=10 / 10 rays per pixel."""
+    case = next(c for c in SMALL if c["name"] == "demo_480x280_b10")
+    px = hip.project_scene(T.golden_scene(case), 480, 280)
+    assert T.fnv(px) == case["fb_fnv"] == "453219f388ade6f2"
+    case = next(c for c in SMALL if c["name"] == "demo_160x48_b4")
+    px = hip.render_frame(T.golden_scene(case), 160, 48, 4, 10)
+    assert T.fnv(px) == case["fb_fnv"]
+    # the scene may change between calls (main() rewrites the camera every frame): new camera, same skybox pointers
+    case2 = next(c for c in SMALL if c["name"] == "demo_160x48_b10")
+    px = hip.render_frame(T.golden_scene(case2), 160, 48, 10, 10)
+    assert T.fnv(px) == case2["fb_fnv"]
+    assert hip.lib().trt_shutdown() == 0
+
+
+def test_counters_equal_reference_trace_ray_counts(ctx):
+    case = next(c for c in SMALL if c["name"] == "synth64_480x270_b8")
+    ctx.enable_counters(True)
+    try:
+        for kernel in KERNELS:
+            px = render(ctx, T.golden_scene(case), 480, 270, 8, 10, kernel)
+            assert T.fnv(px) == case["fb_fnv"]
+            assert ctx.read_counters() == (2966024, 3341736)  # path, shadow
+    finally:
+        ctx.enable_counters(False)
+
+
+def test_north_star_config_production_equals_reference_order_and_oracle(ctx):
+    """BASELINE config 3 at full size: 1920x1080, 64 spheres, 8 bounces, 10 rays per pixel."""
+    w, h = 1920, 1080
+    scene = S.synth_scene(64, S.synth_sky(256), T.bench_camera(w, h), seed=1234)
+    fast = render(ctx, scene, w, h, 8, 10, hip.Context.PRODUCTION)
+    slow = render(ctx, scene, w, h, 8, 10, hip.Context.REFERENCE_ORDER)
+    assert np.array_equal(bits(fast), bits(slow))
+    band, _ = T.oracle_render(scene, w, h, 8, 10, rows=(530, 562))  # rows through the sphere field
+    assert np.array_equal(bits(fast[530:562]), bits(band))
+    assert np.isfinite(fast).all() and fast.min() >= 0.0 and fast.max() <= 1.0
+
+
+@pytest.mark.parametrize("world,tile", [(2, 8), (8, 8), (3, 5)])
+def test_row_tile_shards_reassemble_to_the_whole_frame(ctx, world, tile):
+    case = next(c for c in SMALL if c["name"] == "synth64_128x72_b8")
+    scene = T.golden_scene(case)
+    w, h = 128, 72
+    whole = render(ctx, scene, w, h, 8, 10)
+    out = np.zeros_like(whole)
+    for rank in range(world):
+        rs = hip.RowSet.shard(w, h, rank, world, tile)
+        part = render(ctx, scene, w, h, 8, 10, rows=rs)
+        for i in range(part.shape[0]):
+            out[hip.lib().trt_rowset_frame_row(C.byref(rs), i)] = part[i]
+    assert np.array_equal(bits(out), bits(whole))
+    assert T.fnv(out) == case["fb_fnv"]
+
+
+def test_device_resident_render_and_rgb8_quantisation(ctx):
+    import torch
+    case = next(c for c in SMALL if c["name"] == "demo_160x48_b4")
+    scene = T.golden_scene(case)
+    ctx.set_kernel(hip.Context.PRODUCTION)
+    ctx.set_scene(scene)
+    fb = torch.zeros(48 * 160 * 3, dtype=torch.float64, device="cuda:0")
+    rgb = torch.zeros(48 * 160 * 3, dtype=torch.uint8, device="cuda:0")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.render_device(scene.camera, hip.RowSet.whole(160, 48), 4, 10, fb.data_ptr(), fb.numel() * 8)
+        ctx.quantize_device(fb.data_ptr(), 48 * 160, rgb.data_ptr())
+        torch.cuda.synchronize()
+        assert T.fnv(fb.cpu().numpy()) == case["fb_fnv"]
+        assert T.fnv(rgb.cpu().numpy()) == case["rgb8_fnv"]
+        times = ctx.kernel_times(4)
+        assert len(times) >= 1 and all(t > 0 for t in times)
+        with pytest.raises(hip.TrtError):  # framebuffer too small
+            ctx.render_device(scene.camera, hip.RowSet.whole(160, 48), 4, 10, fb.data_ptr(), 100)
+    finally:
+        ctx.set_stream(None)
+
+
+def test_errors_are_reported_not_swallowed():
+    with hip.Context(0) as c:
+        with pytest.raises(hip.TrtError) as e:
+            c.render_host(np.zeros(15), hip.RowSet.whole(4, 4), 4, 10)
+        assert e.value.code == -3  # TRT_ERR_NO_SCENE
+        case = SMALL[0]
+        c.set_scene(T.golden_scene(case))
+        with pytest.raises(hip.TrtError) as e:
+            c.render_host(T.golden_scene(case).camera, hip.RowSet.whole(4, 4), 0, 10)
+        assert e.value.code == -2
+    with pytest.raises(hip.TrtError):
+        hip.Context(99)
