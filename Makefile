@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 CSRC  := terminalraytracer_amd/csrc
 LIB   := terminalraytracer_amd/libtrt_hip.so
 # -ffp-contract=off: results must be bit-identical to the reference's non-FMA x86-64 build
-HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fPIC -shared -std=c++17 \
+HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -shared -std=c++17 \
             -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
 .PHONY: all lib oracle clean resource-usage

@@ -107,6 +107,7 @@ def main():
     r.render(scene.camera)
     torch.cuda.synchronize()
     path_rays, shadow_rays = r.ctx.read_counters()
+    diag = r.ctx.read_diagnostics()
     r.ctx.enable_counters(False)
     counts = torch.tensor([path_rays, shadow_rays], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
@@ -159,6 +160,7 @@ def main():
                           "peak_tflops_no_fma": FP64_PEAK_TFLOPS / 2,
                           "note": "reference op count 25*N+17 per trace; the kernel does fewer ops than that (FP32 culling)"},
             "kernel_info": r.ctx.kernel_info(),
+            "diagnostics": dict(diag, lane_utilisation=(path_rays + shadow_rays) / max(1, 64 * diag["wave_loop_trips"])),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene)

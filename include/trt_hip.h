@@ -114,6 +114,11 @@ int trt_kernel_times(trt_context *ctx, float *ms, int max);
 int trt_enable_counters(trt_context *ctx, int enable);
 int trt_read_counters(trt_context *ctx, unsigned long long *path_rays, unsigned long long *shadow_rays);
 
+/* Diagnostics of the last counted frame (valid after trt_read_counters, production kernel only):
+ * iterations of the per-wave main loop summed over waves, and exact-test (phase 2) rounds.
+ * Lane utilisation of the trace loop = (path + shadow) / (64 * wave_loop_trips). */
+int trt_read_diagnostics(trt_context *ctx, unsigned long long *wave_loop_trips, unsigned long long *phase2_rounds);
+
 /* Kernel selection: 0 = production kernel; 1 = reference-order debugging kernel (one lane per
  * pixel, no culling).  Both are HIP; there is no CPU path. */
 int trt_set_kernel(trt_context *ctx, int which);

@@ -177,6 +177,21 @@ int trt_oracle_skybox_lookup(const Scene *scene, const Vector *direction, int *f
     return *texel_index >= 0 && *texel_index < (long)dim * dim;
 }
 
+static _Thread_local trt_oracle_ray_log *g_ray_log = NULL;
+
+void trt_oracle_set_ray_log(trt_oracle_ray_log *log) { g_ray_log = log; }
+
+static inline void log_ray(v3 o, v3 d, int kind)
+{
+    trt_oracle_ray_log *l = g_ray_log;
+    if (l && l->count < l->capacity)
+    {
+        double *r = l->rays + 6 * l->count;
+        r[0] = o.x, r[1] = o.y, r[2] = o.z, r[3] = d.x, r[4] = d.y, r[5] = d.z;
+        l->kinds[l->count++] = (unsigned char)kind;
+    }
+}
+
 typedef struct
 {
     ObjectType what;
@@ -289,6 +304,7 @@ static inline v3 lit_color(const Scene *scene, v3 at, v3 normal, v3 albedo, trt_
         const DirectionalLight *l = &scene->directional_lights[i];
         v3 to_light = unit(scale(v3_of(&l->direction), -1.0));
         st->shadow_rays++;
+        log_ray(at, to_light, 1);
         surface blocker = closest_hit(scene, at, to_light, 0);
         if (blocker.what == NONE)
         {
@@ -305,6 +321,7 @@ static inline v3 lit_color(const Scene *scene, v3 at, v3 normal, v3 albedo, trt_
         double strength = clampd(l->intensity / light_d2, 0.0, 1.0);
         to_light = unit(to_light);
         st->shadow_rays++;
+        log_ray(at, to_light, 2);
         surface blocker = closest_hit(scene, at, to_light, 0);
         v3 to_blocker = sub(blocker.point, at); /* on a miss blocker.point == at, so this is 0 */
         double blocker_d2 = dot(to_blocker, to_blocker);
@@ -369,6 +386,7 @@ static inline v3 shade_pixel(const Scene *scene, int width, int height, int row,
         while (going && bounces < bounce_limit && weight > 0.00001) /* TRT.c:1018 */
         {
             st->path_rays++;
+            log_ray(org, dir, 0);
             surface s = closest_hit(scene, org, dir, 1);
             v3 color = v3_of(&s.material.color);
             if (s.what != NONE)

@@ -57,6 +57,18 @@ void trt_oracle_rgb8(const Vector *pixels, size_t count, unsigned char *rgb);
 /* FNV-1a-64, offset 1469598103934665603, prime 1099511628211 */
 unsigned long long trt_oracle_fnv1a64(const void *data, size_t bytes);
 
+/* Ray log for tests: while a log is installed (per thread), every traced ray is appended as
+ * 6 doubles (origin, direction) with kind 0 = path ray, 1 = directional-light shadow ray,
+ * 2 = point-light shadow ray, until capacity is reached.  NULL uninstalls. */
+typedef struct
+{
+    double *rays;
+    unsigned char *kinds;
+    size_t capacity;
+    size_t count;
+} trt_oracle_ray_log;
+void trt_oracle_set_ray_log(trt_oracle_ray_log *log);
+
 /* exact a/b and sqrt(a) tables for the device rounding self-test */
 void trt_oracle_div_sqrt(const double *a, const double *b, size_t n, double *quot, double *root);
 

@@ -90,7 +90,7 @@ struct trt_context
     trt::SceneView scene{};
     trt::CullView cull{};
     int persistent_blocks_per_cu = 0; // occupancy of the production kernel for the current scene's LDS image
-    DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb;
+    DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb, d_axes;
     DeviceBuffer<float> d_cull;
     DeviceBuffer<uint32_t> d_sky;
     DeviceBuffer<unsigned long long> d_counters;
@@ -98,12 +98,15 @@ struct trt_context
     double *h_staging = nullptr; // pinned
     size_t h_staging_bytes = 0;
 
-    // jitter cache key
+    // cache keys of the per-frame tables (jitter; per-column / per-row screen coordinates)
     int jit_spp = -1;
     double jit_pw = 0.0, jit_ph = 0.0;
+    int axes_w = -1, axes_h = -1;
+    double axes_sw = 0.0, axes_sh = 0.0;
 
     int kernel = 0; // 0 production (persistent), 1 reference-order
     bool counters_enabled = false;
+    unsigned long long last_trips = 0, last_phase2 = 0; // diagnostics of the counting kernel variant
 
     hipEvent_t ev_start[kEventRing], ev_stop[kEventRing];
     long launches = 0;
@@ -167,50 +170,21 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
     if (np)
         HIP_TRY(hipMemcpy(ctx->d_point.ptr, scene->point_lights, (size_t)np * sizeof(PointLight), hipMemcpyHostToDevice));
 
-    // FP32 culling table {Cx,Cy,Cz,kk} of trt_filter.h (filter only, never decides a result).
-    // C = c - c0 with c0 the centre of the centres' bounding box; kk = |C|^2 - r^2, both formed in FP64
-    // and then rounded once.  Padded to kCullGroup entries with kk = +inf (never passes).
-    const int padded = (n + trt::kCullGroup - 1) / trt::kCullGroup * trt::kCullGroup;
+    // FP32 culling table {Cx,Cy,Cz,kk} of trt_filter.h (filter only, never decides a result)
+    const int padded = trt_cull_padded(n, trt::kCullGroup);
     std::vector<float> cull((size_t)padded * 4);
-    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    for (int i = 0; i < n; i++)
-    {
-        const double c[3] = {scene->spheres[i].center.x, scene->spheres[i].center.y, scene->spheres[i].center.z};
-        for (int j = 0; j < 3; j++)
-        {
-            lo[j] = (i == 0 || c[j] < lo[j]) ? c[j] : lo[j];
-            hi[j] = (i == 0 || c[j] > hi[j]) ? c[j] : hi[j];
-        }
-    }
-    const double c0[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
-    double cn = 0.0, rm = 0.0;
-    for (int i = 0; i < n; i++)
-    {
-        const Sphere &sp = scene->spheres[i];
-        const double C[3] = {sp.center.x - c0[0], sp.center.y - c0[1], sp.center.z - c0[2]};
-        const double c2 = C[0] * C[0] + C[1] * C[1] + C[2] * C[2];
-        cull[4 * i + 0] = (float)C[0];
-        cull[4 * i + 1] = (float)C[1];
-        cull[4 * i + 2] = (float)C[2];
-        cull[4 * i + 3] = (float)(c2 - sp.radius * sp.radius);
-        cn = std::max(cn, sqrt(c2));
-        rm = std::max(rm, fabs(sp.radius));
-    }
-    for (int i = n; i < padded; i++)
-    {
-        cull[4 * i + 0] = cull[4 * i + 1] = cull[4 * i + 2] = 0.0f;
-        cull[4 * i + 3] = INFINITY;
-    }
+    trt_cull_scene cs;
+    trt_cull_build((const double *)scene->spheres, n, trt::kCullGroup, cull.data(), &cs);
     HIP_TRY(ctx->d_cull.reserve(cull.size()));
     if (padded)
         HIP_TRY(hipMemcpy(ctx->d_cull.ptr, cull.data(), cull.size() * sizeof(float), hipMemcpyHostToDevice));
     ctx->cull.table = ctx->d_cull.ptr;
     ctx->cull.padded = padded;
-    ctx->cull.c0x = c0[0];
-    ctx->cull.c0y = c0[1];
-    ctx->cull.c0z = c0[2];
-    ctx->cull.cn = nextafterf((float)(cn * (1.0 + 1e-6)), INFINITY); // rounded UP
-    ctx->cull.rm = nextafterf((float)(rm * (1.0 + 1e-6)), INFINITY);
+    ctx->cull.c0x = cs.c0[0];
+    ctx->cull.c0y = cs.c0[1];
+    ctx->cull.c0z = cs.c0[2];
+    ctx->cull.cn = cs.cn;
+    ctx->cull.rm = cs.rm;
 
     trt::SceneView &v = ctx->scene;
     v.spheres = ctx->d_spheres.ptr;
@@ -220,12 +194,12 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
     v.num_dir = nd;
     v.num_point = np;
     memcpy(v.ground, &scene->ground, sizeof(Plane));
-    const size_t lds_need = std::max(scene_lds_bytes(v), trt::persistent_lds_bytes(v));
+    const size_t lds_need = std::max(scene_lds_bytes(v), trt::persistent_lds_bytes(v, 64));
     if (lds_need > (size_t)ctx->lds_limit)
         return fail(TRT_ERR_CAPACITY, "scene needs %zu B of LDS staging, device offers %d", lds_need, ctx->lds_limit);
     int blocks = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false>, trt::kPersistentBlock,
-                                                         trt::persistent_lds_bytes(v)));
+                                                         trt::persistent_lds_bytes(v, 64)));
     ctx->persistent_blocks_per_cu = std::max(blocks, 1);
     return TRT_OK;
 }
@@ -248,6 +222,28 @@ int prepare_jitter(trt_context *ctx, const Camera *cam, int width, int height, i
     ctx->jit_spp = spp;
     ctx->jit_pw = pw;
     ctx->jit_ph = ph;
+    return TRT_OK;
+}
+
+// TRT.c:987-988 without the jitter: one value per column and one per frame row, formed on the host in the
+// reference's operation order (this file is compiled with -ffp-contract=off for host and device alike)
+int prepare_axes(trt_context *ctx, const Camera *cam, int width, int height)
+{
+    const double sw = cam->screen_width, sh = cam->screen_height;
+    if (ctx->axes_w == width && ctx->axes_h == height && ctx->axes_sw == sw && ctx->axes_sh == sh)
+        return TRT_OK;
+    std::vector<double> t((size_t)width + height);
+    for (int column = 0; column < width; column++)
+        t[column] = (((double)column / (double)width) * sw - sw / 2.0);
+    for (int row = 0; row < height; row++)
+        t[(size_t)width + row] = -(((double)row / (double)height) * sh - sh / 2.0);
+    HIP_TRY(ctx->d_axes.reserve(t.size()));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(ctx->d_axes.ptr, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->axes_w = width;
+    ctx->axes_h = height;
+    ctx->axes_sw = sw;
+    ctx->axes_sh = sh;
     return TRT_OK;
 }
 
@@ -303,9 +299,9 @@ extern "C" int trt_create(int device, trt_context **out)
         HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
         HIP_TRY(hipEventCreate(&ctx->ev_stop[i]));
     }
-    HIP_TRY(ctx->d_counters.reserve(2));
+    HIP_TRY(ctx->d_counters.reserve(4));
     HIP_TRY(ctx->d_queue.reserve(64));
-    HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int)));
     // dynamic LDS above the 64 KiB default needs the opt-in attribute
     (void)hipFuncSetAttribute((const void *)trt::render_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
@@ -331,6 +327,7 @@ extern "C" int trt_destroy(trt_context *ctx)
     ctx->d_dir.release();
     ctx->d_point.release();
     ctx->d_jitter.release();
+    ctx->d_axes.release();
     ctx->d_fb.release();
     ctx->d_cull.release();
     ctx->d_sky.release();
@@ -371,6 +368,17 @@ extern "C" int trt_set_scene(trt_context *ctx, const Scene *scene)
     return TRT_OK;
 }
 
+extern "C" int trt_read_diagnostics(trt_context *ctx, unsigned long long *wave_loop_trips, unsigned long long *phase2_rounds)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    if (wave_loop_trips)
+        *wave_loop_trips = ctx->last_trips;
+    if (phase2_rounds)
+        *phase2_rounds = ctx->last_phase2;
+    return TRT_OK;
+}
+
 extern "C" int trt_set_kernel(trt_context *ctx, int which)
 {
     if (!ctx || which < 0 || which > 1)
@@ -393,8 +401,10 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long c[2];
+    unsigned long long c[4];
     HIP_TRY(hipMemcpy(c, ctx->d_counters.ptr, sizeof c, hipMemcpyDeviceToHost));
+    ctx->last_trips = c[2];
+    ctx->last_phase2 = c[3];
     if (path_rays)
         *path_rays = c[0];
     if (shadow_rays)
@@ -419,14 +429,23 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
         return fail(TRT_ERR_CAPACITY, "framebuffer needs %zu B, %zu given", need, capacity_bytes);
     if (local_rows == 0)
         return TRT_OK;
+    if ((unsigned long long)local_rows * rows->width >= 0x7fffffffull)
+        return fail(TRT_ERR_ARGUMENT, "%d x %d pixels exceed the 2^31 pixel index range", local_rows, rows->width);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = prepare_jitter(ctx, camera, rows->width, rows->height, rays_per_pixel);
+    if (rc)
+        return rc;
+    rc = prepare_axes(ctx, camera, rows->width, rows->height);
     if (rc)
         return rc;
 
     trt::FrameView f{};
     memcpy(f.cam, camera, sizeof(Camera));
     f.jitter = ctx->d_jitter.ptr;
+    f.col_x = ctx->d_axes.ptr;
+    f.row_y = ctx->d_axes.ptr + rows->width;
+    f.inv_spp = 1.0 / rays_per_pixel;
+    f.width_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rows->width - 1) / (unsigned)rows->width, 0xffffffffull);
     f.out = (double *)d_pixels;
     f.counters = ctx->counters_enabled ? ctx->d_counters.ptr : nullptr;
     f.queue = ctx->d_queue.ptr;
@@ -442,7 +461,7 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
     const long pixels = (long)local_rows * rows->width;
     const size_t lds = scene_lds_bytes(ctx->scene);
     if (ctx->counters_enabled)
-        HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, 4 * sizeof(unsigned long long), ctx->stream));
     const int slot = (int)(ctx->launches % kEventRing);
     if (ctx->kernel == 1)
     {
@@ -456,7 +475,7 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
     {
         HIP_TRY(hipMemsetAsync(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int), ctx->stream));
         const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units, ctx->persistent_blocks_per_cu, pixels);
-        const size_t plds = trt::persistent_lds_bytes(ctx->scene);
+        const size_t plds = trt::persistent_lds_bytes(ctx->scene, rays_per_pixel);
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], ctx->stream));
         if (ctx->counters_enabled)
             hipLaunchKernelGGL(trt::render_persistent_kernel<true>, dim3(pl.grid), dim3(pl.block), plds, ctx->stream, ctx->scene,
@@ -558,7 +577,7 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
     if (max_blocks_per_cu)
     {
         int blocks = 0;
-        const size_t lds = ctx->have_scene ? (ctx->kernel == 1 ? scene_lds_bytes(ctx->scene) : trt::persistent_lds_bytes(ctx->scene)) : 0;
+        const size_t lds = ctx->have_scene ? (ctx->kernel == 1 ? scene_lds_bytes(ctx->scene) : trt::persistent_lds_bytes(ctx->scene, 64)) : 0;
         if (ctx->kernel == 1)
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_simple_kernel, 256, lds));
         else

@@ -88,6 +88,10 @@ struct FrameView
 {
     double cam[15];       // Camera (TRT.c:178): basis x,y,z | origin | screen_distance, screen_width, screen_height
     const double *jitter; // 2*spp doubles: x offsets then y offsets, already scaled by the pixel size (TRT.c:992-993)
+    const double *col_x;  // [width]  (col/W)*screen_width - screen_width/2          (TRT.c:987), formed on the host
+    const double *row_y;  // [height] -((row/H)*screen_height - screen_height/2)     (TRT.c:988), indexed by FRAME row
+    double inv_spp;       // 1.0 / rays_per_pixel (TRT.c:1065)
+    unsigned width_magic; // ceil(2^32 / width): pixel index -> row by multiply-high (persistent kernel)
     double *out;          // compact framebuffer of the owned rows
     unsigned long long *counters; // [path, shadow] or nullptr
     unsigned int *queue;  // work-queue head for the persistent kernel
@@ -210,6 +214,60 @@ TRT_DEV uint32_t sky_texel(const uint32_t *sky, int dim, d3 direction)
         idx = last;
     if (idx < 0)
         idx = 0;
+    return sky[(long)face * dim * dim + idx];
+}
+
+// Same lookup for an ALREADY normalised direction (the caller ran TRT.c:702's normalisation), with the
+// axis-table algebra of TRT.c:705-727 carried out symbolically: multiplying by +-1 or 0 and adding the
+// resulting zeros is exact, so t_f = +-component, scale_by = the winning t, and u, v are +-0.5 * a
+// component of dir*(1/scale_by).  Only the sign of a zero can differ from the table form, and no
+// later step (clamp, +0.5, *dim, truncation) can see it.  Assumes finite components.
+TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir)
+{
+    const double t[6] = {dir.x, -dir.x, dir.y, -dir.y, dir.z, -dir.z};
+    int face = 0;
+    double best = -1.0;
+#pragma unroll
+    for (int f = 0; f < 6; f++)
+        if (t[f] > best) // strict, first wins (TRT.c:708)
+        {
+            best = t[f];
+            face = f;
+        }
+    const double inv = 1.0 / best; // TRT.c:718-719
+    const d3 ds = scale(dir, inv);
+    const int axis = face >> 1;
+    const double sgn = (face & 1) ? -0.5 : 0.5;
+    // u along axes[(face+2)%6], v along axes[(face+4)%6]: same parity of face, next two coordinate axes
+    const double cu = axis == 0 ? ds.y : (axis == 1 ? ds.z : ds.x);
+    const double cv = axis == 0 ? ds.z : (axis == 1 ? ds.x : ds.y);
+    double u = sgn * cu, v = sgn * cv;
+    if (face & 1)
+        u = -u;
+    if (face < 2)
+    {
+        const double w = u;
+        u = v;
+        v = -w;
+    }
+    else if (face < 4)
+    {
+        const double w = u;
+        u = -v;
+        v = w;
+    }
+    else if (face == 4)
+    {
+        u = -u;
+        v = -v;
+    }
+    u = clampd(u, -0.5, 0.5);
+    v = clampd(v, -0.5, 0.5);
+    const int ui = d2i((u + 0.5) * dim);
+    const int vi = d2i((v + 0.5) * dim);
+    long idx = (long)ui + (long)vi * dim;
+    const long last = (long)dim * dim - 1;
+    idx = idx > last ? last : (idx < 0 ? 0 : idx);
     return sky[(long)face * dim * dim + idx];
 }
 

@@ -10,29 +10,35 @@
  * without it.  (tests/test_filter.py checks "exact hit => filter passes" on millions of rays
  * with this very code compiled for the host.)
  *
- * Formulation.  With C = c - c0 (c0 = a per-scene shift, e.g. the centre of the spheres'
- * bounding box), O = o - c0, a = d.d, dh = d/sqrt(a), P = O - ((O.d)/a) d (the part of O
- * perpendicular to the ray), W = 2P, Kc = -|P|^2, kk = |C|^2 - r^2:
+ * Formulation.  With C = c - c0 (c0 = a per-scene shift: the centre of the sphere centres'
+ * bounding box), O = o - c0, a = d.d and O' = O - (O.d) d, which is a point of the ray's LINE for
+ * any a (the closest one to c0 when a = 1); kk = |C|^2 - r^2:
  *
- *      disc / (4a)  =  (C.dh)^2 + C.W - kk + Kc            (exact algebra)
- *      (o-c).d      =  O.d - sqrt(a) (C.dh)
+ *      disc / (4a)  =  (b' - cd)^2 + 2 C.O' - kk - |O'|^2 ,   cd = (C.d)/sqrt(a),  b' = (O'.d)/sqrt(a)
+ *      (o-c).d      =  O.d - C.d                                                   (exact algebra)
  *
- * Per ray (FP64, then rounded to FP32): dh, W, Kc and two thresholds.  Per sphere (FP32, table
- * {Cx,Cy,Cz,kk}): two 3-term dot products by FMA and one more FMA, two compares.
+ * Every ray the renderer traces has been normalised (TRT.c:1008, :1055, :904, :933), so
+ * a = 1 +- a few ulp.  The filter therefore evaluates with a := 1 and b' := 0,
  *
- *      pass  <=>  !( fma(cd,cd, C.W - kk) < thr )  &&  !( cd < cd_min )       cd = C.dh
+ *      pass  <=>  !( fma(cd,cd, C.W - kk) < thr )  &&  !( cd < cd_min ),    cd = C.d (FP32), W = 2 O'
  *
- * thr = -Kc - E and cd_min = ((O.d) - Eb)/sqrt(a) - slack, where E and Eb bound the total
- * rounding error of the FP32 evaluation PLUS the reference's own FP64 rounding
+ * and a ray with |a - 1| > 2^-40 (a degenerate, un-normalisable direction) simply passes every
+ * sphere on to the exact test.  Per ray the set-up is 19 FP64 add/mul (no division, no sqrt),
+ * 8 conversions and a dozen FP32 ops; per sphere 7 FP32 FMA/mul and 2 compares on a
+ * scalar-loaded table {Cx,Cy,Cz,kk}.
+ *
+ * thr = |O'|^2 - E and cd_min = O.d - Eb, where E and Eb bound the total rounding error of the
+ * FP32 evaluation PLUS the reference's own FP64 rounding PLUS the a := 1 approximation
  * (eps = 2^-24, u = 2^-53; Cn >= max|C|, Rm >= max r, Wn = |W|_1 >= |W|, On = |O|_1 >= |O|):
  *
- *      |error of the FP32 left-hand side|  <=  eps (20 Cn^2 + 8 Cn Wn + 6 Rm^2 + Wn^2/2)   ("filter bound")
- *                                          <=  20 eps (Cn + Wn + Rm)^2
- *      E  = 40 eps (Cn + Wn + Rm)^2 + 256 u (On + Cn + Rm)^2          (2x head-room; FP64 terms)
- *      Eb = 32 eps (Cn + |O.d|/sqrt(a)) sqrt(a) ...                    (see code)
+ *      FP32 evaluation:   <= eps (20 Cn^2 + 8 Cn Wn + 6 Rm^2 + Wn^2/2)  <=  20 eps (Cn + Wn + Rm)^2
+ *      a := 1, b' := 0:   <= 2^-39 (On + Cn)^2  =  2^14 u (On + Cn)^2
+ *      FP64 (set-up, and the reference's own disc):  <= 64 u (On + Cn + Rm)^2
+ *      E  = 40 eps (Cn + Wn + Rm)^2 + 2^16 u (On + Cn + Rm)^2          (>= 2x head-room on each)
+ *      Eb = 32 eps (Cn + |O.d|) + 2^16 u (On + Cn + Rm)
  *
- * Every comparison is written so that NaN/inf (a == 0, overflow) PASS the sphere on to the
- * exact test.  The second condition uses: b = 2 (o-c).d >= 0  =>  t0 <= 0  => miss.
+ * Every comparison is written so that NaN/inf PASS the sphere on to the exact test.  The
+ * second condition uses: b = 2 (o-c).d >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0  =>  miss.
  */
 #ifndef TRT_FILTER_H
 #define TRT_FILTER_H
@@ -60,6 +66,50 @@ typedef struct
     float rm;     /* >= max_i r_i, rounded up */
 } trt_cull_scene;
 
+/* Build the culling table for n spheres given as the reference's 9-double Sphere records
+ * (TRT.c:161-166: centre xyz, radius, material...).  table must hold 4*padded floats where
+ * padded = n rounded up to a multiple of `group`; pad entries carry kk = +inf and never pass.
+ * C = c - c0 with c0 the centre of the centres' bounding box; kk = |C|^2 - r^2; both are formed
+ * in FP64 and rounded once. */
+static inline int trt_cull_padded(int n, int group) { return (n + group - 1) / group * group; }
+
+static inline void trt_cull_build(const double *spheres, int n, int group, float *table, trt_cull_scene *cs)
+{
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++)
+        {
+            const double c = spheres[9 * i + j];
+            lo[j] = (i == 0 || c < lo[j]) ? c : lo[j];
+            hi[j] = (i == 0 || c > hi[j]) ? c : hi[j];
+        }
+    for (int j = 0; j < 3; j++)
+        cs->c0[j] = 0.5 * (lo[j] + hi[j]);
+    double cn = 0.0, rm = 0.0;
+    for (int i = 0; i < n; i++)
+    {
+        const double C0 = spheres[9 * i] - cs->c0[0], C1 = spheres[9 * i + 1] - cs->c0[1], C2 = spheres[9 * i + 2] - cs->c0[2];
+        const double r = spheres[9 * i + 3];
+        const double c2 = C0 * C0 + C1 * C1 + C2 * C2;
+        table[4 * i + 0] = (float)C0;
+        table[4 * i + 1] = (float)C1;
+        table[4 * i + 2] = (float)C2;
+        table[4 * i + 3] = (float)(c2 - r * r);
+        const double cl = __builtin_sqrt(c2), ra = __builtin_fabs(r);
+        cn = cl > cn ? cl : cn;
+        rm = ra > rm ? ra : rm;
+    }
+    const int padded = trt_cull_padded(n, group);
+    for (int i = n; i < padded; i++)
+    {
+        table[4 * i + 0] = table[4 * i + 1] = table[4 * i + 2] = 0.0f;
+        table[4 * i + 3] = __builtin_inff();
+    }
+    /* rounded UP: the bounds must not be under-estimated */
+    cs->cn = __builtin_nextafterf((float)(cn * (1.0 + 1e-6)), __builtin_inff());
+    cs->rm = __builtin_nextafterf((float)(rm * (1.0 + 1e-6)), __builtin_inff());
+}
+
 #define TRT_EPS32 5.9604644775390625e-08f /* 2^-24 */
 #define TRT_U64F 1.1102230246251565e-16f  /* 2^-53 as float */
 
@@ -68,28 +118,25 @@ TRT_HD void trt_filter_setup(trt_ray_filter *f, double ox, double oy, double oz,
 {
     const double Ox = ox - c0x, Oy = oy - c0y, Oz = oz - c0z;
     const double od = Ox * dx + Oy * dy + Oz * dz;
-    const double s = 1.0 / a;
-    const double t = od * s;
-    const double Px = Ox - t * dx, Py = Oy - t * dy, Pz = Oz - t * dz;
-    const double rs = __builtin_sqrt(s);
-    f->dx = (float)(dx * rs);
-    f->dy = (float)(dy * rs);
-    f->dz = (float)(dz * rs);
+    const double Px = Ox - od * dx, Py = Oy - od * dy, Pz = Oz - od * dz; /* O' */
+    f->dx = (float)dx;
+    f->dy = (float)dy;
+    f->dz = (float)dz;
     f->wx = (float)(2.0 * Px);
     f->wy = (float)(2.0 * Py);
     f->wz = (float)(2.0 * Pz);
-    const float kc = (float)(Px * Px + Py * Py + Pz * Pz); /* -Kc */
+    const float kc = (float)(Px * Px + Py * Py + Pz * Pz); /* |O'|^2 */
     const float wn = __builtin_fabsf(f->wx) + __builtin_fabsf(f->wy) + __builtin_fabsf(f->wz);
     const float on = (float)(__builtin_fabs(Ox) + __builtin_fabs(Oy) + __builtin_fabs(Oz));
     const float m32 = cn + wn + rm;
     const float m64 = on + cn + rm;
-    const float E = 40.0f * TRT_EPS32 * m32 * m32 + 256.0f * TRT_U64F * m64 * m64;
-    /* thr = -Kc - E = kc - E, pushed down by the rounding of kc itself and of this subtraction */
-    f->thr = kc - E - 4.0f * TRT_EPS32 * kc;
-    /* cd_min: (o-c).d = od - cd/rs  <= Eb  <=>  cd >= (od - Eb) rs */
-    const float odr = (float)(od * rs);
-    const float Eb = 32.0f * TRT_EPS32 * (cn + __builtin_fabsf(odr)) + 256.0f * TRT_U64F * m64;
-    f->cd_min = odr - Eb;
+    const float E = 40.0f * TRT_EPS32 * m32 * m32 + 65536.0f * TRT_U64F * m64 * m64;
+    const float odf = (float)od;
+    const float Eb = 32.0f * TRT_EPS32 * (cn + __builtin_fabsf(odf)) + 65536.0f * TRT_U64F * m64;
+    const int unit_ray = __builtin_fabs(a - 1.0) <= 9.094947017729282e-13; /* 2^-40; false for NaN */
+    /* thr is pushed down by the rounding of kc itself and of the subtraction */
+    f->thr = unit_ray ? kc - E - 4.0f * TRT_EPS32 * kc : -__builtin_inff();
+    f->cd_min = unit_ray ? odf - Eb : -__builtin_inff();
 }
 
 TRT_HD int trt_filter_pass(const trt_ray_filter *f, float cx, float cy, float cz, float kk)

@@ -2,29 +2,33 @@
 //
 // Shape of the work: per pixel `spp` samples, per sample a bounce loop, per bounce
 // one closest-hit trace plus one shadow trace per light; a trace = N sphere tests + 1 plane test.
-// >95 % of the time is sphere tests, and path length varies 1..bounce_limit per sample.
+// Path length varies 1..bounce_limit per sample, so neighbouring pixels differ ~10x in cost.
 //
 // Design:
 //   * PERSISTENT waves, ONE LANE = ONE PIXEL AT A TIME.  A lane runs its pixel's samples in
 //     order (the mean over samples must be accumulated in the reference's order, TRT.c:1063)
 //     and, when the pixel is finished, pulls the next pixel index from a global queue
-//     (wave-aggregated atomic).  Lanes therefore never idle while pixels remain, however
-//     different the path lengths of neighbouring pixels are.
+//     (wave-aggregated atomic).  Lanes never idle while pixels remain.
 //   * ONE TRACE LOOP FOR EVERY KIND OF RAY.  Path rays (TRT.c:1024) and the shadow rays of
-//     lighting (TRT.c:907, :937) are the same closest-hit search, so the lane keeps a tiny
+//     lighting (TRT.c:907, :937) are the same closest-hit search, so each lane keeps a small
 //     state machine (mode = PATH | SHADOW(light i)) and all 64 lanes of a wave -- whatever
 //     their mode -- go through the sphere sweep together.  The reference's recursion
 //     (apply_lighting -> trace_ray) becomes "re-enter the loop with the shadow ray".
 //   * TWO-PHASE SPHERE SWEEP.  Phase 1: wave-uniform loop over a FP32 culling table read with
-//     scalar loads (sphere index is uniform, so the table rides in SGPRs), 9 FP32 VALU ops per
-//     sphere, result = per-lane 64-bit candidate mask (trt_filter.h; conservative, never decides
-//     a hit).  Phase 2: each lane pops its own candidates in ascending index order and runs the
-//     EXACT FP64 test in the reference's operation order against sphere records in LDS
-//     (per-lane index -> LDS gather).  The divergent, expensive part (sqrt, divide) thus runs
-//     max-over-lanes(candidates) ~ 2-4 times per trace instead of once per sphere.
-//   * Scene records (spheres SoA, materials, lights) are staged once per workgroup into LDS;
-//     the cubemap (6*dim*dim texels, 1.5 MB at 256^2, does not fit the 160 KB LDS) stays in
-//     global memory / L2 and is touched once per sample.
+//     scalar loads (the sphere index is uniform, so the table rides in SGPRs): 7 FP32 VALU ops
+//     + 2 compares per sphere, result = per-lane candidate bit mask (trt_filter.h;
+//     conservative, never decides a hit).  Phase 2: each lane pops its own candidates in
+//     ascending index order and runs the EXACT FP64 test in the reference's operation order
+//     against sphere records in LDS (per-lane index -> LDS gather).
+//   * ONE SHARED NORMALISATION STAGE PER ITERATION.  FP64 sqrt and division are ~18 and ~11
+//     instructions each and the reference normalises vectors everywhere (3 divisions each).
+//     A lane's post-trace work is therefore split into POST (cheap, per mode: decide what
+//     happens next, emit up to two vectors to normalise and one quotient), NORM (all lanes
+//     together: two unit() slots, one division) and FINISH (cheap, per mode: consume them).
+//     Divergent per-mode code holds only adds/multiplies; the long sequences run convergent.
+//   * Scene records are staged once per workgroup into LDS (spheres SoA, materials, lights,
+//     a byte/255.0 table); the cubemap (1.5 MB at 256^2) does not fit the 160 KB LDS and stays
+//     in global memory / L2, touched once per sample.
 //   * FP64 throughout, contraction off: results are bit-identical to the reference.
 #pragma once
 
@@ -35,7 +39,7 @@ namespace trt
 {
 
 constexpr int kPersistentBlock = 256;
-constexpr int kCullGroup = 16; // culling-table entries fetched per scalar-load batch (table padded to this)
+constexpr int kCullGroup = 8;  // culling-table entries fetched per scalar-load batch (table padded to this)
 
 struct PersistentLaunch
 {
@@ -50,10 +54,13 @@ inline PersistentLaunch persistent_launch_shape(int compute_units, int blocks_pe
 }
 
 // LDS image: cx[n] cy[n] cz[n] r2[n] | mat[(n+2)*5] (spheres, ground even, ground odd) |
-//            dir lights: unit to-light(3) colour(3) | point lights: pos(3) colour(3) intensity
-inline size_t persistent_lds_bytes(const SceneView &s)
+//            dir lights: unit to-light(3) colour(3) | point lights: pos(3) colour(3) intensity | byte/255.0 [256] |
+//            camera: basis x,y,z (9) eye (3) -screen_distance (1) | jitter x[spp] y[spp]
+constexpr int kLdsCameraDoubles = 13;
+inline size_t persistent_lds_bytes(const SceneView &s, int spp)
 {
-    return sizeof(double) * ((size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * 6 + (size_t)s.num_point * 7);
+    return sizeof(double) * ((size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * 6 +
+                             (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp);
 }
 
 struct CullView
@@ -64,15 +71,14 @@ struct CullView
     float cn, rm;
 };
 
+typedef const float __attribute__((address_space(4))) *const_float_ptr;
+
+// modes of a lane between two traces
 enum : int
 {
-    kDone = 0,
-    kNeedPixel = 1,
-    kNeedPrimary = 2,
-    kTrace = 3
+    kModeBoot = -1, // has no pixel yet
+    kModePath = 0   // 1 + i: shadow ray of light i (directional lights first, then point lights)
 };
-
-typedef const float __attribute__((address_space(4))) *const_float_ptr;
 
 template <bool COUNT>
 __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(SceneView s, CullView cull, FrameView f)
@@ -83,6 +89,9 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
     double *const l_mat = l_r2 + n;
     double *const l_dir = l_mat + (n + 2) * 5;
     double *const l_pt = l_dir + nd * 6;
+    double *const l_255 = l_pt + np * 7;
+    double *const l_cam = l_255 + 256;         // rarely-used frame constants live in LDS, not in SGPRs
+    double *const l_jit = l_cam + kLdsCameraDoubles;
 
     for (int i = threadIdx.x; i < n; i += blockDim.x)
     {
@@ -105,87 +114,57 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
     }
     for (int i = threadIdx.x; i < np * 7; i += blockDim.x)
         l_pt[i] = s.point_lights[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x)
+        l_255[i] = (double)i / 255.0; // TRT.c:866
+    for (int i = threadIdx.x; i < 12; i += blockDim.x)
+        l_cam[i] = f.cam[i];
+    if (threadIdx.x == 0)
+        l_cam[12] = -f.cam[12]; // TRT.c:989
+    for (int i = threadIdx.x; i < 2 * f.spp; i += blockDim.x)
+        l_jit[i] = f.jitter[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const long total = (long)f.local_rows * f.width;
-    const d3 eye = load3(f.cam + 9);
+    const unsigned total = (unsigned)f.local_rows * (unsigned)f.width; // < 2^31, checked by the host
     const d3 gp = load3(s.ground), gn = load3(s.ground + 3);
     const const_float_ptr table = (const_float_ptr)(uintptr_t)cull.table;
 
-    // ---- per-lane state ------------------------------------------------------------------------
-    int state = kNeedPixel;
-    long pix = 0;
-    int k = 0;                    // sample index within the pixel
-    d3 mean = d3{0.0, 0.0, 0.0};  // sum over samples (average_pixel_color, TRT.c:977)
+    // ---- per-lane state --------------------------------------------------------------------------------
+    bool alive = true;   // false once the queue is empty and this lane has written its last pixel
+    bool has_ray = false;
+    int mode = kModeBoot;
+    unsigned pix = 0;
+    double sx_base = 0.0, sy_base = 0.0; // screen coordinates of the pixel before jitter (TRT.c:987-988)
+    int k = 0;                     // sample index within the pixel
+    d3 mean = d3{0.0, 0.0, 0.0};   // sum over samples (average_pixel_color, TRT.c:977)
     d3 sample = d3{0.0, 0.0, 0.0}; // pixel_color of the current sample (TRT.c:1012)
     double weight = 1.0, weight_sum = 0.0;
     int bounces = 0;
-    d3 o = eye, d = d3{0.0, 0.0, 1.0}; // the ray being traced
-    int mode = 0;                      // 0: path ray; 1+i: shadow ray of light i (directional lights first)
+    d3 o = d3{0.0, 0.0, 0.0}, d = d3{0.0, 0.0, -1.0};
     // surface found by the path ray, kept while its shadow rays are traced
-    d3 h_point = eye, h_normal = d, path_dir = d, lit = d3{0.0, 0.0, 0.0};
-    int h_mat = 0;                     // index into l_mat (sphere i, n = ground even, n+1 = ground odd)
+    d3 h_point = o, h_normal = d, path_dir = d, lit = d3{0.0, 0.0, 0.0};
+    int h_mat = 0; // index into l_mat (sphere i, n = ground even, n+1 = ground odd)
     double light_d2 = 0.0, strength = 0.0;
-    unsigned n_path = 0, n_shadow = 0;
+    unsigned n_path = 0, n_shadow = 0, n_trips = 0, n_phase2 = 0;
 
-    for (;;)
+    while (__any(alive))
     {
-        // ---- take new pixels from the queue (wave-aggregated) --------------------------------------
-        const unsigned long long need = __ballot(state == kNeedPixel);
-        if (need)
-        {
-            unsigned base = 0;
-            const int leader = __builtin_ctzll(need);
-            if (lane == leader)
-                base = atomicAdd(f.queue, (unsigned)__builtin_popcountll(need));
-            base = __shfl(base, leader);
-            if (state == kNeedPixel)
-            {
-                const long mine = (long)base + __builtin_popcountll(need & ((1ull << lane) - 1ull));
-                if (mine < total)
-                {
-                    pix = mine;
-                    k = 0;
-                    mean = d3{0.0, 0.0, 0.0};
-                    state = kNeedPrimary;
-                }
-                else
-                    state = kDone;
-            }
-        }
-        if (!__any(state != kDone))
-            break;
-
-        // ---- primary ray of sample k (TRT.c:981-1016) ------------------------------------------------
-        if (state == kNeedPrimary)
-        {
-            const int local_row = (int)(pix / f.width), column = (int)(pix - (long)local_row * f.width);
-            d = primary_direction(f, frame_row_of(f, local_row), column, k);
-            o = eye;
-            sample = d3{0.0, 0.0, 0.0};
-            weight = 1.0;
-            weight_sum = 0.0;
-            bounces = 0;
-            mode = 0;
-            state = kTrace;
-        }
-        const bool active = state == kTrace;
-
-        // ---- closest hit (TRT.c:793-856) -----------------------------------------------------------
+        if (COUNT)
+            n_trips++;
+        // =================================== TRACE (TRT.c:793-856) ===================================
         const double a = dot(d, d);
         double best_d2 = __builtin_inf();
         d3 best_p = o;
         int best_i = -1; // sphere index, or n for the ground
-        if (COUNT && active)
+        if (COUNT && has_ray)
         {
-            if (mode == 0)
+            if (mode == kModePath)
                 n_path++;
             else
                 n_shadow++;
         }
         // a directional-light shadow ray only asks "anything hit?" (TRT.c:908): any hit ends its search
-        const bool any_hit_suffices = mode != 0 && mode <= nd;
+        const bool any_hit_suffices = mode >= 1 && mode <= nd;
 
         trt_ray_filter flt;
         trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
@@ -207,11 +186,13 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
                 }
                 cand |= (unsigned long long)bits << g;
             }
-            if (!active)
+            if (!has_ray)
                 cand = 0;
             // phase 2: exact FP64 tests of this lane's candidates, ascending index (first index wins ties)
             while (__any(cand != 0))
             {
+                if (COUNT)
+                    n_phase2++;
                 if (cand != 0)
                 {
                     const int i = base + __builtin_ctzll(cand);
@@ -245,7 +226,7 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
             }
         }
         // ground plane (TRT.c:831-853)
-        if (active && !(any_hit_suffices && best_i >= 0))
+        if (has_ray && !(any_hit_suffices && best_i >= 0))
         {
             d3 p;
             if (hit_plane(o, d, gp, gn, p))
@@ -260,116 +241,269 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
             }
         }
 
-        // ---- what the lane does with the result -----------------------------------------------------
-        bool sample_done = false, lighting_done = false, next_shadow = false;
-        int li = 0;
-        if (active && mode == 0)
+        // =================================== POST ===================================
+        // Decide what this lane does next; emit the vectors to normalise (uA, uB) and one quotient (qn/qd).
+        d3 uA = d3{0.0, 0.0, 1.0}, uB = d3{0.0, 0.0, 1.0};
+        double qn = 0.0, qd = 1.0;
+        bool needA = false, needB = false;
+        bool path_hit = false, path_sky = false, shadow_back = false, lighting_done = false;
+        bool end_sample = false, end_pixel = false, want_pixel = false;
+        double weight_sum_new = weight_sum, light_d2_next = 0.0;
+        const bool hit = best_i >= 0;
+        if (has_ray && mode == kModePath)
         {
-            if (best_i < 0)
-            { // sky (TRT.c:858-867, :1044-1048): colour = texel, reflectivity 0, the sample ends
-                const d3 color = texel_color(sky_texel(s.sky, s.sky_dim, d));
-                weight_sum += weight;
-                sample = add(sample, scale(color, weight));
-                sample_done = true;
-            }
-            else
+            if (hit)
             {
-                h_point = nudge(o, best_p); // TRT.c:871-874
+                path_hit = true;
+                uA = sub(o, best_p); // nudge direction, TRT.c:871-872
+                needA = true;
                 if (best_i < n)
                 {
-                    h_normal = unit(sub(best_p, d3{l_cx[best_i], l_cy[best_i], l_cz[best_i]})); // TRT.c:824, :878
+                    uB = sub(best_p, d3{l_cx[best_i], l_cy[best_i], l_cz[best_i]}); // TRT.c:824
                     h_mat = best_i;
                 }
                 else
                 {
-                    h_normal = unit(gn);
+                    uB = gn;
                     h_mat = n + checker_odd(best_p); // TRT.c:850-851
                 }
-                path_dir = d;
-                lit = d3{0.0, 0.0, 0.0};
-                if (nl > 0)
-                    next_shadow = true;
-                else
-                    lighting_done = true;
-            }
-        }
-        else if (active)
-        {
-            // shadow ray of light `mode-1` came back (TRT.c:908-922 / :939-956); d is the unit vector to the light
-            li = mode - 1;
-            bool is_lit;
-            double factor;
-            d3 lcolor;
-            if (li < nd)
-            {
-                is_lit = best_i < 0;
-                factor = min1(dot(h_normal, d));
-                lcolor = load3(l_dir + li * 6 + 3);
+                needB = true;
             }
             else
             {
-                is_lit = best_i < 0;
-                if (!is_lit)
-                { // blocker farther than the light?  distance to the NUDGED blocker point (TRT.c:939-942)
-                    const d3 to_blocker = sub(nudge(o, best_p), o);
-                    is_lit = light_d2 < dot(to_blocker, to_blocker);
-                }
-                factor = strength * min1(dot(h_normal, d));
-                lcolor = load3(l_pt + (li - nd) * 7 + 3);
+                path_sky = true; // TRT.c:858-867, :1044-1048: the sample ends on the sky
+                uA = d;          // get_skybox_color normalises the direction again, TRT.c:702
+                needA = true;
+                end_sample = true;
             }
-            if (is_lit)
-                lit = add(lit, mulc(scale(lcolor, factor), load3(l_mat + h_mat * 5)));
-            li++;
-            if (li < nl)
-                next_shadow = true;
+        }
+        else if (has_ray)
+        {
+            shadow_back = true;
+            const int li = mode - 1;
+            if (li >= nd && hit)
+            { // point light with a blocker: is the blocker farther than the light?  needs the nudged point (TRT.c:939-942)
+                uA = sub(o, best_p);
+                needA = true;
+            }
+            if (li + 1 < nl)
+            {
+                if (li + 1 >= nd)
+                { // next light is a point light: TRT.c:929-933
+                    const double *pl = l_pt + (li + 1 - nd) * 7;
+                    uB = sub(load3(pl), h_point);
+                    light_d2_next = dot(uB, uB);
+                    qn = pl[6];
+                    qd = light_d2_next;
+                    needB = true;
+                }
+            }
             else
                 lighting_done = true;
         }
-
+        else if (alive && mode >= 1)
+            lighting_done = true; // a scene without lights: the surface found last iteration is shaded black
         if (lighting_done)
-        { // TRT.c:960-962 then :1034-1056
-            d3 color = d3{clampd(lit.x, 0.0, 1.0), clampd(lit.y, 0.0, 1.0), clampd(lit.z, 0.0, 1.0)};
-            weight_sum += weight;
-            color = scale(color, weight);
-            weight *= l_mat[h_mat * 5 + 3];
-            bounces++;
-            sample = add(sample, color);
-            d = unit(reflect(path_dir, h_normal));
-            o = h_point;
-            mode = 0;
-            if (!(bounces < f.bounce_limit && weight > 0.00001)) // TRT.c:1018
-                sample_done = true;
-        }
-        if (next_shadow)
-        { // shadow ray towards light li (TRT.c:903-907 / :929-937)
-            if (li < nd)
-                d = load3(l_dir + li * 6);
-            else
+        { // does the bounce loop go on after this surface?  TRT.c:1018, :1041-1042
+            const double w_next = weight * l_mat[h_mat * 5 + 3];
+            if (bounces + 1 < f.bounce_limit && w_next > 0.00001)
             {
-                const double *pl = l_pt + (li - nd) * 7;
+                uB = reflect(path_dir, h_normal); // TRT.c:1054
+                needB = true;
+            }
+            else
+                end_sample = true;
+        }
+        int k_next = k;
+        if (end_sample)
+        {
+            weight_sum_new = weight_sum + weight; // TRT.c:1034
+            qn = 1.0;
+            qd = weight_sum_new; // TRT.c:1061
+            k_next = k + 1;
+            if (k_next == f.spp)
+            {
+                end_pixel = true;
+                k_next = 0;
+            }
+        }
+        want_pixel = alive && (end_pixel || mode == kModeBoot);
+        unsigned pix_next = pix;
+        double sx_next = sx_base, sy_next = sy_base;
+        {
+            const unsigned long long need = __ballot(want_pixel);
+            if (need)
+            { // wave-aggregated pull from the pixel queue
+                unsigned first = 0;
+                const int leader = __builtin_ctzll(need);
+                if (lane == leader)
+                    first = atomicAdd(f.queue, (unsigned)__builtin_popcountll(need));
+                first = __shfl(first, leader);
+                if (want_pixel)
+                {
+                    pix_next = first + (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+                    if (pix_next < total)
+                    { // row = pix / width by multiply-high with min(ceil(2^32/width), 2^32-1): off by at most one
+                        unsigned row = __umulhi(pix_next, f.width_magic);
+                        int col = (int)(pix_next - row * (unsigned)f.width);
+                        if (col < 0)
+                        {
+                            row--;
+                            col += f.width;
+                        }
+                        else if (col >= f.width)
+                        {
+                            row++;
+                            col -= f.width;
+                        }
+                        sx_next = f.col_x[col];
+                        sy_next = f.row_y[frame_row_of(f, (int)row)];
+                    }
+                }
+            }
+        }
+        const bool new_sample = (end_sample || mode == kModeBoot) && alive && pix_next < total;
+        if (new_sample)
+        { // primary ray of sample k_next of pixel pix_next (TRT.c:987-1005); normalised in NORM
+            const double sx = sx_next + l_jit[k_next];
+            const double sy = sy_next + l_jit[f.spp + k_next];
+            d3 dir = d3{0.0, 0.0, 0.0};
+            dir = add(dir, scale(load3(l_cam + 0), sx));
+            dir = add(dir, scale(load3(l_cam + 3), sy));
+            dir = add(dir, scale(load3(l_cam + 6), l_cam[12]));
+            uB = sub(dir, load3(l_cam + 9)); // sic, TRT.c:1005
+            needB = true;
+        }
+
+        // =================================== NORM (convergent) ===================================
+        d3 nA = uA, nB = uB;
+        double q = 0.0;
+        if (__any(needA))
+            nA = unit(uA);
+        if (__any(needB))
+            nB = unit(uB);
+        if (__any(end_sample || (shadow_back && needB)))
+            q = qn / qd;
+
+        // =================================== FINISH ===================================
+        if (path_hit)
+        {
+            h_point = add(best_p, scale(nA, 0.000001)); // TRT.c:873-874
+            h_normal = nB;                              // TRT.c:878
+            path_dir = d;
+            lit = d3{0.0, 0.0, 0.0};
+            o = h_point;
+            if (nl == 0)
+            {
+                has_ray = false; // nothing to trace: shaded black next iteration
+                mode = 1;
+            }
+            else if (nd > 0)
+            {
+                d = load3(l_dir); // TRT.c:903-907
+                mode = 1;
+            }
+            else
+            { // first light is a point light: its direction depends on h_point, which only now exists
+                const double *pl = l_pt;
                 d3 to_light = sub(load3(pl), h_point);
                 light_d2 = dot(to_light, to_light);
                 strength = clampd(pl[6] / light_d2, 0.0, 1.0);
                 d = unit(to_light);
+                mode = 1;
             }
-            o = h_point;
-            mode = li + 1;
         }
-        if (sample_done)
-        { // TRT.c:1061-1066
-            sample = scale(sample, 1.0 / weight_sum);
-            mean = add(mean, sample);
-            k++;
-            if (k < f.spp)
-                state = kNeedPrimary;
+        else if (shadow_back)
+        { // TRT.c:908-922 / :939-956; d is the unit vector to the light
+            const int li = mode - 1;
+            bool is_lit = !hit;
+            double factor = min1(dot(h_normal, d));
+            d3 lcolor;
+            if (li < nd)
+                lcolor = load3(l_dir + li * 6 + 3);
             else
             {
-                mean = scale(mean, 1.0 / f.spp);
-                double *out = f.out + pix * 3;
+                if (hit)
+                {
+                    const d3 to_blocker = sub(add(best_p, scale(nA, 0.000001)), o);
+                    is_lit = light_d2 < dot(to_blocker, to_blocker);
+                }
+                factor = strength * factor;
+                lcolor = load3(l_pt + (li - nd) * 7 + 3);
+            }
+            if (is_lit)
+                lit = add(lit, mulc(scale(lcolor, factor), load3(l_mat + h_mat * 5)));
+            if (!lighting_done)
+            { // next shadow ray from the same surface point (o stays h_point)
+                if (li + 1 < nd)
+                    d = load3(l_dir + (li + 1) * 6);
+                else
+                {
+                    d = nB;
+                    light_d2 = light_d2_next;
+                    strength = clampd(q, 0.0, 1.0);
+                }
+                mode = li + 2;
+            }
+        }
+        if (lighting_done)
+        { // TRT.c:960-962 then :1034-1056
+            d3 color = d3{clampd(lit.x, 0.0, 1.0), clampd(lit.y, 0.0, 1.0), clampd(lit.z, 0.0, 1.0)};
+            if (!end_sample)
+                weight_sum += weight;
+            color = scale(color, weight);
+            weight *= l_mat[h_mat * 5 + 3];
+            bounces++;
+            sample = add(sample, color);
+            if (!end_sample)
+            {
+                d = nB;
+                o = h_point;
+                mode = kModePath;
+                has_ray = true;
+            }
+        }
+        if (path_sky)
+        { // colour of the sky texel (TRT.c:865-866); the sample ends
+            const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, nA);
+            const d3 color = d3{l_255[t & 0xFF], l_255[(t >> 8) & 0xFF], l_255[(t >> 16) & 0xFF]};
+            sample = add(sample, scale(color, weight));
+        }
+        if (end_sample)
+        { // TRT.c:1061-1066
+            sample = scale(sample, q);
+            mean = add(mean, sample);
+            if (end_pixel)
+            {
+                mean = scale(mean, f.inv_spp);
+                double *out = f.out + (size_t)pix * 3;
                 out[0] = mean.x;
                 out[1] = mean.y;
                 out[2] = mean.z;
-                state = kNeedPixel;
+                mean = d3{0.0, 0.0, 0.0};
+            }
+        }
+        if (end_sample || mode == kModeBoot)
+        {
+            if (new_sample)
+            {
+                pix = pix_next;
+                sx_base = sx_next;
+                sy_base = sy_next;
+                k = k_next;
+                d = nB;
+                o = load3(l_cam + 9);
+                sample = d3{0.0, 0.0, 0.0};
+                weight = 1.0;
+                weight_sum = 0.0;
+                bounces = 0;
+                mode = kModePath;
+                has_ray = true;
+            }
+            else
+            {
+                alive = false;
+                has_ray = false;
             }
         }
     }
@@ -378,6 +512,11 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
     {
         atomicAdd(&f.counters[0], (unsigned long long)n_path);
         atomicAdd(&f.counters[1], (unsigned long long)n_shadow);
+        if (lane == 0)
+        { // diagnostics: loop trips and phase-2 rounds per wave (lane utilisation = traces / (64 * trips))
+            atomicAdd(&f.counters[2], (unsigned long long)n_trips);
+            atomicAdd(&f.counters[3], (unsigned long long)n_phase2);
+        }
     }
 }
 

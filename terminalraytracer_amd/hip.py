@@ -63,6 +63,7 @@ SYMBOLS = {
     "trt_kernel_times": (_I, [_VP, C.POINTER(C.c_float), _I]),
     "trt_enable_counters": (_I, [_VP, _I]),
     "trt_read_counters": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "trt_read_diagnostics": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "trt_set_kernel": (_I, [_VP, _I]),
     "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
     "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
@@ -174,6 +175,11 @@ class Context:
         p, s = C.c_ulonglong(), C.c_ulonglong()
         _check(lib().trt_read_counters(self._h, C.byref(p), C.byref(s)))
         return p.value, s.value
+
+    def read_diagnostics(self):
+        t, p = C.c_ulonglong(), C.c_ulonglong()
+        _check(lib().trt_read_diagnostics(self._h, C.byref(t), C.byref(p)))
+        return {"wave_loop_trips": t.value, "phase2_rounds": p.value}
 
     def kernel_info(self):
         v = [_I() for _ in range(5)]

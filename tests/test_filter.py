@@ -1,0 +1,152 @@
+"""The FP32 culling filter of the production kernel (csrc/trt_filter.h) must be CONSERVATIVE:
+whenever the exact reference test (FP64, TRT.c:638-672) reports a hit, the filter must have let
+that sphere through.  The very header the kernel compiles is compiled for the host here and
+driven with (a) every ray the oracle traces in real frames and (b) adversarial rays: grazing
+tangents, far origins, non-unit directions, tiny/huge/far-away spheres."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import support as T
+from terminalraytracer_amd import scenes as S
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_ulonglong), ("pairs", C.c_ulonglong), ("exact_hits", C.c_ulonglong),
+                ("line_hits", C.c_ulonglong), ("passed", C.c_ulonglong), ("violations", C.c_ulonglong),
+                ("cand_hist", C.c_ulonglong * 17), ("hit_hist", C.c_ulonglong * 17),
+                ("wave_max_cand", C.c_ulonglong), ("wave_groups", C.c_ulonglong), ("first_violation", C.c_double * 8)]
+
+
+class RayLog(C.Structure):
+    _fields_ = [("rays", C.c_void_p), ("kinds", C.c_void_p), ("capacity", C.c_size_t), ("count", C.c_size_t)]
+
+
+@pytest.fixture(scope="module")
+def checker():
+    build = os.path.join(T.ROOT, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    so = os.path.join(build, "libfiltercheck.so")
+    src = os.path.join(T.ROOT, "tests", "filter_check.c")
+    hdr = os.path.join(T.ROOT, "terminalraytracer_amd", "csrc", "trt_filter.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+                               "-I" + os.path.dirname(hdr), "-o", so, src, "-lm"])
+    lib = C.CDLL(so)
+    lib.filter_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Stats)]
+    lib.filter_check.restype = None
+    return lib
+
+
+def run(checker, spheres, rays):
+    spheres = np.ascontiguousarray(spheres, dtype=np.float64).reshape(-1, 9)
+    rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+    st = Stats()
+    checker.filter_check(spheres.ctypes.data, spheres.shape[0], rays.ctypes.data, rays.shape[0], C.byref(st))
+    return st
+
+
+def traced_rays(scene, w, h, b, spp, cap=4_000_000):
+    """every ray the oracle traces for this frame (single thread, in trace order)"""
+    rays = np.zeros((cap, 6))
+    kinds = np.zeros(cap, dtype=np.uint8)
+    log = RayLog(rays.ctypes.data, kinds.ctypes.data, cap, 0)
+    lib = T.oracle()
+    lib.trt_oracle_set_ray_log.argtypes = [C.POINTER(RayLog)]
+    lib.trt_oracle_set_ray_log(C.byref(log))
+    try:
+        T.oracle_render(scene, w, h, b, spp, threads=1)
+    finally:
+        lib.trt_oracle_set_ray_log(None)
+    return rays[: log.count], kinds[: log.count]
+
+
+def describe(st):
+    r = max(st.rays, 1)
+    return (f"rays {st.rays} pairs {st.pairs} exact hits/ray {st.exact_hits / r:.3f} line hits/ray {st.line_hits / r:.3f} "
+            f"candidates/ray {st.passed / r:.3f} max-candidates per 64 rays {st.wave_max_cand / max(st.wave_groups, 1):.2f} "
+            f"cand hist {list(st.cand_hist)[:8]}")
+
+
+FRAMES = [("north-star scene, 64 spheres", lambda: S.synth_scene(64, T.sky("synth"), T.bench_camera(240, 135)), 240, 135, 8),
+          ("demo scene", lambda: S.demo_scene(T.sky("synth"), T.bench_camera(160, 90)), 160, 90, 10),
+          ("256 spheres", lambda: S.synth_scene(256, T.sky("synth"), T.bench_camera(96, 54)), 96, 54, 12),
+          ("mirror-heavy", lambda: S.synth_scene(64, T.sky("synth"), T.bench_camera(96, 54, 10.0), mirror_fraction=0.5), 96, 54, 8)]
+
+
+@pytest.mark.parametrize("name,make,w,h,b", FRAMES, ids=[f[0] for f in FRAMES])
+def test_filter_never_rejects_a_hit_on_real_frames(checker, name, make, w, h, b):
+    scene = make()
+    rays, kinds = traced_rays(scene, w, h, b, 10)
+    assert len(rays) > 10000
+    st = run(checker, scene.spheres, rays)
+    print(name, describe(st))
+    assert st.violations == 0, list(st.first_violation)
+    assert st.exact_hits > 0
+    # the filter must actually cull: far fewer candidates than pairs, and close to the true line hits
+    assert st.passed < 0.1 * st.pairs
+
+
+def _tangent_rays(rng, spheres, n, rel_offsets):
+    """rays grazing spheres: origin somewhere, aimed at a point at distance r*(1+offset) from the centre"""
+    idx = rng.integers(0, len(spheres), n)
+    c, r = spheres[idx, :3], spheres[idx, 3]
+    org = c + rng.normal(size=(n, 3)) * rng.uniform(1.5, 50.0, (n, 1)) * np.maximum(r[:, None], 1e-3)
+    to_c = c - org
+    dist = np.linalg.norm(to_c, axis=1, keepdims=True)
+    axis = np.cross(to_c, rng.normal(size=(n, 3)))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    rr = (r * (1.0 + rng.choice(rel_offsets, n)))[:, None]
+    # direction making angle asin(rr/dist) with to_c: passes at distance rr from the centre
+    sin_t = np.clip(rr / dist, -1, 1)
+    cos_t = np.sqrt(1 - sin_t ** 2)
+    d = to_c / dist * cos_t + axis * sin_t
+    return np.concatenate([org, d], axis=1)
+
+
+def test_filter_is_conservative_on_adversarial_rays(checker):
+    rng = np.random.default_rng(7)
+    total_hits = 0
+    for trial in range(12):
+        n_s = int(rng.integers(1, 80))
+        centre_scale = 10.0 ** rng.uniform(-1, 4)       # spheres spread 0.1 .. 1e4
+        shift = rng.normal(size=3) * 10.0 ** rng.uniform(-2, 5)  # whole scene far from the origin
+        sph = np.zeros((n_s, 9))
+        sph[:, :3] = rng.normal(size=(n_s, 3)) * centre_scale + shift
+        sph[:, 3] = 10.0 ** rng.uniform(-4, 1, n_s) * centre_scale * 0.1
+        sph[:, 4:] = 0.5
+        offs = np.array([0.0, 1e-16, -1e-16, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3])
+        rays = [_tangent_rays(rng, sph, 20000, offs)]
+        # random rays from near and far, non-unit directions
+        o = shift + rng.normal(size=(20000, 3)) * centre_scale * 10.0 ** rng.uniform(-1, 3, (20000, 1))
+        tgt = sph[rng.integers(0, n_s, 20000), :3] + rng.normal(size=(20000, 3)) * sph[:, 3].mean()
+        d = (tgt - o)
+        d *= 10.0 ** rng.uniform(-3, 3, (20000, 1)) / np.linalg.norm(d, axis=1, keepdims=True)
+        rays.append(np.concatenate([o, d], axis=1))
+        # rays that start ON a sphere surface (reflection / shadow rays do)
+        k = rng.integers(0, n_s, 20000)
+        nrm = rng.normal(size=(20000, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        o = sph[k, :3] + nrm * sph[k, 3][:, None] * (1 + 1e-9)
+        d = rng.normal(size=(20000, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays.append(np.concatenate([o, d], axis=1))
+        st = run(checker, sph, np.concatenate(rays))
+        total_hits += st.exact_hits
+        assert st.violations == 0, (trial, list(st.first_violation))
+    assert total_hits > 50000
+
+
+def test_degenerate_rays_pass_everything_to_the_exact_test(checker):
+    sph = S.synth_spheres(8)
+    rays = np.array([[0, 0, 5, 0, 0, 0],                # zero direction: a == 0
+                     [0, 0, 5, np.nan, 0, -1],
+                     [np.inf, 0, 5, 0, 0, -1],
+                     [0, 0, 5, 1e-200, 0, 0],           # a underflows to 0
+                     [1e200, 0, 0, -1, 0, 0]], dtype=np.float64)
+    st = run(checker, sph, rays)
+    assert st.violations == 0
+    assert st.passed == st.pairs  # nothing may be culled on NaN/inf evidence

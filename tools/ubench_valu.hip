@@ -1,0 +1,138 @@
+// ubench_valu.hip -- issue cost of the VALU instructions the frame producer is made of, on gfx950.
+// Each kernel runs ITER x 32 copies of one instruction on 8 independent register sets and stamps
+// s_memtime around the loop; cycles per wave-instruction are reported at 1, 2 and 4 waves per SIMD.
+// Build: hipcc --offload-arch=gfx950 -O2 -o /tmp/ubench tools/ubench_valu.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+#define ITER 2000
+#define REP8(x) x(0) x(1) x(2) x(3) x(4) x(5) x(6) x(7)
+
+#define KERNEL(NAME, DECL, BODY, SINK)                                                                   \
+    __global__ void k_##NAME(unsigned long long *out, double seed)                                       \
+    {                                                                                                    \
+        DECL                                                                                             \
+        unsigned long long t0, t1;                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");                        \
+        for (int it = 0; it < ITER; it++)                                                                \
+        {                                                                                                \
+            BODY BODY BODY BODY                                                                          \
+        }                                                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");                        \
+        SINK                                                                                             \
+        if ((threadIdx.x & 63) == 0)                                                                     \
+            out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;                                 \
+    }
+
+#define D64 double a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7, b = seed * 0.5 + 1e-3, c = 1.0000001;
+#define S64 if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678) out[0] = 1;
+#define D32 float a0 = (float)seed, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7, b = a0 * 0.5f + 1e-3f, c = 1.0000001f;
+#define S32 if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678f) out[0] = 1;
+#define DI unsigned a0 = (unsigned)seed, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7, b = a0 * 3 + 1, c = 7;
+#define SI if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345) out[0] = 1;
+
+#define X_FMA64(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a##i) : "v"(c), "v"(b));
+#define X_MUL64(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a##i) : "v"(c));
+#define X_ADD64(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define X_RCP64(i) asm volatile("v_rcp_f64 %0, %0" : "+v"(a##i));
+#define X_RSQ64(i) asm volatile("v_rsq_f64 %0, %0" : "+v"(a##i));
+#define X_DSC64(i) asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(a##i) : "v"(b) : "vcc");
+#define X_DFM64(i) asm volatile("v_div_fmas_f64 %0, %0, %1, %2" : "+v"(a##i) : "v"(c), "v"(b) : "vcc");
+#define X_DFX64(i) asm volatile("v_div_fixup_f64 %0, %0, %1, %2" : "+v"(a##i) : "v"(c), "v"(b));
+#define X_LDX64(i) asm volatile("v_ldexp_f64 %0, %0, 1" : "+v"(a##i));
+#define X_CMP64(i) asm volatile("v_cmp_lt_f64 vcc, %0, %1" ::"v"(a##i), "v"(b) : "vcc");
+#define X_FMA32(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a##i) : "v"(c), "v"(b));
+#define X_FMAC32(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a##i) : "v"(c), "v"(b));
+#define X_CMP32(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(a##i), "v"(b) : "vcc");
+#define X_CMP32S(i) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" ::"v"(a##i), "v"(b) : "s20", "s21");
+#define X_CND(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##i) : "v"(b) : "vcc");
+#define X_MOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a##i) : "v"(b));
+#define X_OR3(i) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+#define X_ADDC(i) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(a##i)::"vcc");
+#define X_CVT(i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a##i) : "v"(bd));
+#define X_RDL(i) asm volatile("v_readlane_b32 s20, %0, 3" ::"v"(a##i) : "s20");
+
+KERNEL(fma_f64, D64, REP8(X_FMA64), S64)
+KERNEL(mul_f64, D64, REP8(X_MUL64), S64)
+KERNEL(add_f64, D64, REP8(X_ADD64), S64)
+KERNEL(rcp_f64, D64, REP8(X_RCP64), S64)
+KERNEL(rsq_f64, D64, REP8(X_RSQ64), S64)
+KERNEL(div_scale_f64, D64, REP8(X_DSC64), S64)
+KERNEL(div_fmas_f64, D64, REP8(X_DFM64), S64)
+KERNEL(div_fixup_f64, D64, REP8(X_DFX64), S64)
+KERNEL(ldexp_f64, D64, REP8(X_LDX64), S64)
+KERNEL(cmp_f64, D64, REP8(X_CMP64), S64)
+KERNEL(fma_f32, D32, REP8(X_FMA32), S32)
+KERNEL(fmac_f32, D32, REP8(X_FMAC32), S32)
+KERNEL(cmp_f32_vcc, D32, REP8(X_CMP32), S32)
+KERNEL(cmp_f32_sgpr, D32, REP8(X_CMP32S), S32)
+KERNEL(cndmask_b32, DI, REP8(X_CND), SI)
+KERNEL(mov_b32, DI, REP8(X_MOV), SI)
+KERNEL(or3_b32, DI, REP8(X_OR3), SI)
+KERNEL(addc_u32, DI, REP8(X_ADDC), SI)
+KERNEL(readlane, DI, REP8(X_RDL), SI)
+__global__ void k_cvt_f32_f64(unsigned long long *out, double seed)
+{
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+    double bd = seed;
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < ITER; it++)
+    {
+        REP8(X_CVT) REP8(X_CVT) REP8(X_CVT) REP8(X_CVT)
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.f)
+        out[0] = 1;
+    if ((threadIdx.x & 63) == 0)
+        out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
+typedef void (*kern_t)(unsigned long long *, double);
+struct Entry
+{
+    const char *name;
+    kern_t fn;
+};
+
+int main()
+{
+    Entry list[] = {{"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64}, {"v_rcp_f64", k_rcp_f64},
+                    {"v_rsq_f64", k_rsq_f64}, {"v_div_scale_f64", k_div_scale_f64}, {"v_div_fmas_f64", k_div_fmas_f64},
+                    {"v_div_fixup_f64", k_div_fixup_f64}, {"v_ldexp_f64", k_ldexp_f64}, {"v_cmp_lt_f64", k_cmp_f64},
+                    {"v_cvt_f32_f64", k_cvt_f32_f64}, {"v_fma_f32", k_fma_f32}, {"v_fmac_f32", k_fmac_f32},
+                    {"v_cmp_lt_f32 vcc", k_cmp_f32_vcc}, {"v_cmp_lt_f32 sgpr", k_cmp_f32_sgpr}, {"v_cndmask_b32", k_cndmask_b32},
+                    {"v_mov_b32", k_mov_b32}, {"v_or3_b32", k_or3_b32}, {"v_addc_co_u32", k_addc_u32}, {"v_readlane_b32", k_readlane}};
+    unsigned long long *d;
+    hipMalloc(&d, 1 << 20);
+    printf("%-20s %10s %10s %10s %10s   (cycles per wave-instruction per SIMD = wave cycles / instrs * waves... see columns)\n", "instruction",
+           "1w/SIMD", "2w/SIMD", "3w/SIMD", "4w/SIMD");
+    for (auto &e : list)
+    {
+        printf("%-20s", e.name);
+        for (int w = 1; w <= 4; w++)
+        {
+            const int block = 256 * w; // 4 SIMDs x w waves, one block per CU
+            const int grid = 256;
+            if (block > 1024)
+            { // 2 blocks per CU of 512
+            }
+            const int b = block > 1024 ? 512 : block, g = block > 1024 ? grid * (block / 512) : grid;
+            hipLaunchKernelGGL(e.fn, dim3(g), dim3(b), 0, 0, d, 1.25);
+            hipDeviceSynchronize();
+            hipLaunchKernelGGL(e.fn, dim3(g), dim3(b), 0, 0, d, 1.25);
+            hipDeviceSynchronize();
+            const int waves = g * b / 64;
+            std::vector<unsigned long long> h(waves);
+            hipMemcpy(h.data(), d, waves * 8, hipMemcpyDeviceToHost);
+            std::sort(h.begin(), h.end());
+            const double med = (double)h[waves / 2];
+            // s_memtime ticks at a constant 100 MHz on gfx9; report SIMD-cycles per instruction instead through wall: use ratio to fma_f32 later
+            printf(" %10.3f", med / (ITER * 32.0) / w);
+        }
+        printf("\n");
+    }
+    return 0;
+}
