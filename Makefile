@@ -1,26 +1,45 @@
-# Top-level build: libtrt_hip.so (HIP kernels + C-ABI, gfx950 only) and the CPU checkers under oracle/.
+# Top-level build: libtrt_hip.so (HIP kernels + C-ABI + host-side C, gfx950 only), the C demo driver and
+# the CPU checkers under oracle/.
 HIPCC ?= /opt/rocm/bin/hipcc
+CC    ?= gcc
 CSRC  := terminalraytracer_amd/csrc
 LIB   := terminalraytracer_amd/libtrt_hip.so
-# -ffp-contract=off: results must be bit-identical to the reference's non-FMA x86-64 build
-HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -shared -std=c++17 \
+BUILD := build
+# -ffp-contract=off: results must be bit-identical to the reference's non-FMA x86-64 build.
+# -fno-slp-vectorize: packed FP32 (v_pk_fma_f32) buys nothing on gfx950 and costs registers.
+HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -std=c++17 \
             -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+HOSTFLAGS := -O2 -ffp-contract=off -fno-fast-math -fPIC -std=c11 -Iinclude -Wall -Wextra
+HOST_SRC := $(wildcard $(CSRC)/host/*.c)
+HOST_OBJ := $(patsubst $(CSRC)/host/%.c,$(BUILD)/host_%.o,$(HOST_SRC))
 
-.PHONY: all lib oracle clean resource-usage
-all: lib oracle
+.PHONY: all lib demo oracle clean resource-usage
+all: lib demo oracle
 
 lib: $(LIB)
 
-$(LIB): $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/host/*.c) include/trt.h include/trt_hip.h
-	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/host/*.c)
+$(BUILD)/host_%.o: $(CSRC)/host/%.c include/trt.h include/trt_host.h
+	@mkdir -p $(BUILD)
+	$(CC) $(HOSTFLAGS) -c -o $@ $<
+
+$(BUILD)/trt_capi.o: $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/trt_capi.hip
+
+$(LIB): $(BUILD)/trt_capi.o $(HOST_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(BUILD)/trt_capi.o $(HOST_OBJ)
+
+demo: examples/trt_demo
+examples/trt_demo: examples/trt_demo.c $(LIB) include/trt_hip.h include/trt_host.h
+	$(CC) -O2 -std=c11 -Iinclude -o $@ $< -Lterminalraytracer_amd -ltrt_hip -lm -Wl,-rpath,'$$ORIGIN/../terminalraytracer_amd'
 
 oracle:
 	$(MAKE) -C oracle all
 
 # compiler's view of registers / LDS / occupancy per kernel
 resource-usage:
-	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -o /tmp/trt_ru.so $(CSRC)/trt_capi.hip 2>&1 | grep -E "remark" || true
+	$(HIPCC) $(HIPFLAGS) -shared -Rpass-analysis=kernel-resource-usage -o /tmp/trt_ru.so $(CSRC)/trt_capi.hip 2>&1 | grep -E "remark" || true
 
 clean:
-	rm -f $(LIB)
+	rm -rf $(LIB) $(BUILD) examples/trt_demo
 	$(MAKE) -C oracle clean

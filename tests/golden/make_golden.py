@@ -302,7 +302,7 @@ def main():
         ref = RefLib.get(b, 10, w, h)
         px = ref.render(demo("colors", cam1), w, h)
         ref.lib.initialize_screenbuffer()
-        size = (6 + 1) + ((25) * w + 1) * h + 1  # sizeof(screenbuffer), TerminalRayTracer.c:1104
+        size = (7 + 1) + (25 * w + 1) * h + 1  # sizeof(screenbuffer), TerminalRayTracer.c:1104: (sizeof(reset_str)+1) + ...
         buf = (C.c_char * size).in_dll(ref.lib, "screenbuffer")
         # patch digits exactly as buffered_draw_screen does, without its fwrite to stdout:
         # call it with stdout redirected to /dev/null
