@@ -3,11 +3,13 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 CC    ?= gcc
 CSRC  := terminalraytracer_amd/csrc
-LIB   := terminalraytracer_amd/libtrt_hip.so
+LIB   ?= terminalraytracer_amd/libtrt_hip.so
 BUILD := build
 # -ffp-contract=off: results must be bit-identical to the reference's non-FMA x86-64 build.
 # -fno-slp-vectorize: packed FP32 (v_pk_fma_f32) buys nothing on gfx950 and costs registers.
-HIPFLAGS := --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -std=c++17 \
+# extra -D switches for kernel-tuning A/B builds, e.g. make lib LIB=build/w4.so TUNE=-DTRT_PERSISTENT_WAVES=4
+TUNE ?=
+HIPFLAGS := $(TUNE) --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -std=c++17 \
             -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 HOSTFLAGS := -O2 -ffp-contract=off -fno-fast-math -fPIC -std=c11 -Iinclude -Wall -Wextra
 HOST_SRC := $(wildcard $(CSRC)/host/*.c)
@@ -22,12 +24,12 @@ $(BUILD)/host_%.o: $(CSRC)/host/%.c include/trt.h include/trt_host.h
 	@mkdir -p $(BUILD)
 	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
-$(BUILD)/trt_capi.o: $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h
+$(BUILD)/trt_capi$(subst =,_,$(subst -D,_,$(TUNE))).o: $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/trt_capi.hip
 
-$(LIB): $(BUILD)/trt_capi.o $(HOST_OBJ)
-	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(BUILD)/trt_capi.o $(HOST_OBJ)
+$(LIB): $(BUILD)/trt_capi$(subst =,_,$(subst -D,_,$(TUNE))).o $(HOST_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $< $(HOST_OBJ)
 
 demo: examples/trt_demo
 examples/trt_demo: examples/trt_demo.c $(LIB) include/trt_hip.h include/trt_host.h

@@ -44,36 +44,48 @@ def algorithmic_bytes(width, height, n, dim, ld, lp):
 
 
 def cpu_baseline(scene):
-    """Reference CPU path on this box's host cores, on a bounded sample: the same scene and camera
-    at 960x540 (1/4 of the pixels), one frame, single thread like the reference itself."""
+    """Reference CPU path on this box's host cores: the genuine reference (oracle/_ref, compiled from the
+    reference's own file) renders ONE frame of the same workload, single-threaded like the original
+    (about 10-15 s of CPU work).  Falls back to the repo's restatement ("port") where the reference
+    library is absent.  The all-core OpenMP port is reported beside it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import support as T
     from terminalraytracer_amd import layout as L
     from terminalraytracer_amd import scenes as S
-    sw, sh = W // 2, H // 2
-    _, st = T.oracle_render(scene, sw, sh, BOUNCES, SPP)  # ray count of the sample (multi-threaded, untimed)
+    threads = min(os.cpu_count() or 1, 64)
+    t0 = time.perf_counter()
+    _, st = T.oracle_render(scene, W, H, BOUNCES, SPP, threads=threads)  # also yields the ray count of the frame
+    dt_all = time.perf_counter() - t0
     ref = os.path.join(ROOT, "oracle", "_ref", f"libtrtref_b{BOUNCES}_s{SPP}_w480_h280.so")
-    out = {"unit": "path rays/s", "cores": 1, "sample": f"{sw}x{sh} frame (1/4 of the pixels) of the same scene/camera, 1 frame"}
+    out = {"unit": "path rays/s", "cores": 1, "sample": f"1 full {W}x{H} frame of the same scene/camera (the whole step)"}
     if os.path.exists(ref):
         lib = C.CDLL(ref)
         lib.project_scene.argtypes = [C.POINTER(L.Scene), C.POINTER(L.Screen)]
         sc = scene.as_scene()
-        screen, px = S.new_screen(sw, sh)
+        screen, px = S.new_screen(W, H)
         t0 = time.perf_counter()
         lib.project_scene(C.byref(sc), C.byref(screen))
         dt = time.perf_counter() - t0
         out.update(kind="reference", value=st.path_rays / dt, seconds=dt)
     else:
         t0 = time.perf_counter()
-        T.oracle_render(scene, sw, sh, BOUNCES, SPP, threads=1)
+        T.oracle_render(scene, W, H, BOUNCES, SPP, threads=1)
         dt = time.perf_counter() - t0
         out.update(kind="port", value=st.path_rays / dt, seconds=dt)
-    threads = min(os.cpu_count() or 1, 64)
-    t0 = time.perf_counter()
-    T.oracle_render(scene, sw, sh, BOUNCES, SPP, threads=threads)
-    dt = time.perf_counter() - t0
-    out["port_all_cores"] = {"value": st.path_rays / dt, "cores": threads, "seconds": dt}
+    out["port_all_cores"] = {"value": st.path_rays / dt_all, "cores": threads, "seconds": dt_all}
+    out["path_rays_in_sample"] = st.path_rays
     return out
+
+
+def measured_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic.json; FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        t = json.load(fh)
+    return t.get("hbm_bytes_per_launch"), t
 
 
 def main():
@@ -83,6 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=0, help="0 production, 1 reference-order (debug)")
+    ap.add_argument("--units", type=int, default=0, help="work units of the production kernel: 0 auto, 1 pixels, 2 samples")
     args = ap.parse_args()
 
     import torch
@@ -101,6 +114,7 @@ def main():
     scene = build_scene()
     r = HipShardRenderer(scene, W, H, rank, world, local, BOUNCES, SPP)
     r.ctx.set_kernel(args.kernel)
+    r.ctx.set_work_units(args.units)
 
     # untimed: per-frame ray counts of this rank's rows (counting variant of the kernel)
     r.ctx.enable_counters(True)
@@ -154,8 +168,9 @@ def main():
             "all_rays_per_s": (path_total + shadow_total) * args.steps / seconds,
             "kernel_ms_avg": kavg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "note": "FP64-VALU-bound path: algorithmic HBM bytes are ~1 B/ray (SURVEY 8d); see fp64_valu"},
+                         "traffic": measured_traffic()[0] if world == 1 else None,
+                         "algorithmic_bytes": alg,
+                         "note": "VALU-issue-bound path: algorithmic HBM bytes are ~1 B/ray (SURVEY 8d); see fp64_valu and DESIGN.md 5"},
             "fp64_valu": {"achieved_tflops_reference_opcount": flops / (kavg * 1e-3) / 1e12, "peak_tflops_fma": FP64_PEAK_TFLOPS,
                           "peak_tflops_no_fma": FP64_PEAK_TFLOPS / 2,
                           "note": "reference op count 25*N+17 per trace; the kernel does fewer ops than that (FP32 culling)"},

@@ -123,6 +123,12 @@ int trt_read_diagnostics(trt_context *ctx, unsigned long long *wave_loop_trips, 
  * pixel, no culling).  Both are HIP; there is no CPU path. */
 int trt_set_kernel(trt_context *ctx, int which);
 
+/* Work units of the production kernel: 0 = automatic (default), 1 = whole pixels (the lane keeps the running
+ * mean of TRT.c:1063), 2 = single samples (per-sample colours go to a scratch buffer, a second kernel forms
+ * the mean in the reference's order).  Samples balance ten times finer and are chosen automatically when a
+ * frame (or a GPU's shard of it) has few pixels per resident lane; results are bit-identical either way. */
+int trt_set_work_units(trt_context *ctx, int units);
+
 /* Resource usage of the selected render kernel (hipFuncGetAttributes / occupancy query). */
 int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *static_lds_bytes, int *max_blocks_per_cu,
                     int *compute_units);

@@ -90,7 +90,7 @@ struct trt_context
     trt::SceneView scene{};
     trt::CullView cull{};
     int persistent_blocks_per_cu = 0; // occupancy of the production kernel for the current scene's LDS image
-    DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb, d_axes;
+    DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb, d_axes, d_samples;
     DeviceBuffer<float> d_cull;
     DeviceBuffer<uint32_t> d_sky;
     DeviceBuffer<unsigned long long> d_counters;
@@ -105,6 +105,7 @@ struct trt_context
     double axes_sw = 0.0, axes_sh = 0.0;
 
     int kernel = 0; // 0 production (persistent), 1 reference-order
+    int units = 0;  // work units of the production kernel: 0 automatic, 1 pixels, 2 samples
     bool counters_enabled = false;
     unsigned long long last_trips = 0, last_phase2 = 0; // diagnostics of the counting kernel variant
 
@@ -198,7 +199,7 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
     if (lds_need > (size_t)ctx->lds_limit)
         return fail(TRT_ERR_CAPACITY, "scene needs %zu B of LDS staging, device offers %d", lds_need, ctx->lds_limit);
     int blocks = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false>, trt::kPersistentBlock,
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false, false>, trt::kPersistentBlock,
                                                          trt::persistent_lds_bytes(v, 64)));
     ctx->persistent_blocks_per_cu = std::max(blocks, 1);
     return TRT_OK;
@@ -299,15 +300,17 @@ extern "C" int trt_create(int device, trt_context **out)
         HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
         HIP_TRY(hipEventCreate(&ctx->ev_stop[i]));
     }
-    HIP_TRY(ctx->d_counters.reserve(4));
+    HIP_TRY(ctx->d_counters.reserve(12));
     HIP_TRY(ctx->d_queue.reserve(64));
-    HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, 12 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int)));
     // dynamic LDS above the 64 KiB default needs the opt-in attribute
     (void)hipFuncSetAttribute((const void *)trt::render_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::probe_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
-    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
-    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     *out = ctx;
     return TRT_OK;
 }
@@ -328,6 +331,7 @@ extern "C" int trt_destroy(trt_context *ctx)
     ctx->d_point.release();
     ctx->d_jitter.release();
     ctx->d_axes.release();
+    ctx->d_samples.release();
     ctx->d_fb.release();
     ctx->d_cull.release();
     ctx->d_sky.release();
@@ -387,6 +391,14 @@ extern "C" int trt_set_kernel(trt_context *ctx, int which)
     return TRT_OK;
 }
 
+extern "C" int trt_set_work_units(trt_context *ctx, int units)
+{
+    if (!ctx || units < 0 || units > 2)
+        return fail(TRT_ERR_ARGUMENT, "units %d", units);
+    ctx->units = units;
+    return TRT_OK;
+}
+
 extern "C" int trt_enable_counters(trt_context *ctx, int enable)
 {
     if (!ctx)
@@ -401,10 +413,19 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long c[4];
+    unsigned long long c[12];
     HIP_TRY(hipMemcpy(c, ctx->d_counters.ptr, sizeof c, hipMemcpyDeviceToHost));
     ctx->last_trips = c[2];
     ctx->last_phase2 = c[3];
+    if (getenv("TRT_PRINT_STAMPS"))
+    { // diagnostic builds only (-DTRT_STAMP=1): per-stage wave-cycle sums
+        static const char *const names[8] = {"filter set-up", "phase 1 sweep", "phase 2 exact", "plane", "POST", "NORM", "FINISH", "loop edge"};
+        unsigned long long total = 0;
+        for (int i = 0; i < 8; i++)
+            total += c[4 + i];
+        for (int i = 0; i < 8 && total; i++)
+            fprintf(stderr, "stamp %-14s %6.2f %%  %llu\n", names[i], 100.0 * c[4 + i] / total, c[4 + i]);
+    }
     if (path_rays)
         *path_rays = c[0];
     if (shadow_rays)
@@ -461,7 +482,7 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
     const long pixels = (long)local_rows * rows->width;
     const size_t lds = scene_lds_bytes(ctx->scene);
     if (ctx->counters_enabled)
-        HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, 4 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, 12 * sizeof(unsigned long long), ctx->stream));
     const int slot = (int)(ctx->launches % kEventRing);
     if (ctx->kernel == 1)
     {
@@ -474,15 +495,38 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
     else
     {
         HIP_TRY(hipMemsetAsync(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int), ctx->stream));
-        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units, ctx->persistent_blocks_per_cu, pixels);
+        const long lanes = (long)ctx->compute_units * ctx->persistent_blocks_per_cu * trt::kPersistentBlock;
+        // pixels as work units need many of them per lane to balance (a pixel is 10..240 traces); otherwise samples
+        const bool sample_units = ctx->units == 2 || (ctx->units == 0 && pixels < 48 * lanes);
+        const long units = sample_units ? pixels * rays_per_pixel : pixels;
+        if ((unsigned long long)units >= 0x7fffffffull)
+            return fail(TRT_ERR_ARGUMENT, "%ld work units exceed the 2^31 index range", units);
+        if (sample_units)
+        {
+            if (ctx->d_samples.capacity < (size_t)units * 3)
+                HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still use the old scratch
+            HIP_TRY(ctx->d_samples.reserve((size_t)units * 3));
+            f.samples = ctx->d_samples.ptr;
+            f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
+        }
+        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units, ctx->persistent_blocks_per_cu, units);
         const size_t plds = trt::persistent_lds_bytes(ctx->scene, rays_per_pixel);
+        const dim3 grid(pl.grid), block(pl.block);
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], ctx->stream));
-        if (ctx->counters_enabled)
-            hipLaunchKernelGGL(trt::render_persistent_kernel<true>, dim3(pl.grid), dim3(pl.block), plds, ctx->stream, ctx->scene,
-                               ctx->cull, f);
+        if (sample_units)
+        {
+            if (ctx->counters_enabled)
+                hipLaunchKernelGGL((trt::render_persistent_kernel<true, true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+            else
+                hipLaunchKernelGGL((trt::render_persistent_kernel<false, true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+            const long values = pixels * 3;
+            hipLaunchKernelGGL(trt::reduce_samples_kernel, dim3((unsigned)((values + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const double *)ctx->d_samples.ptr, (double *)d_pixels, values, rays_per_pixel, f.inv_spp);
+        }
+        else if (ctx->counters_enabled)
+            hipLaunchKernelGGL((trt::render_persistent_kernel<true, false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
         else
-            hipLaunchKernelGGL(trt::render_persistent_kernel<false>, dim3(pl.grid), dim3(pl.block), plds, ctx->stream, ctx->scene,
-                               ctx->cull, f);
+            hipLaunchKernelGGL((trt::render_persistent_kernel<false, false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
         HIP_TRY(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
     }
     HIP_TRY(hipGetLastError());
@@ -565,7 +609,7 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
     if (!ctx)
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel : (const void *)trt::render_persistent_kernel<false>;
+    const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel : (const void *)trt::render_persistent_kernel<false, false>;
     hipFuncAttributes attr;
     HIP_TRY(hipFuncGetAttributes(&attr, fn));
     if (vgprs)
@@ -581,7 +625,7 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
         if (ctx->kernel == 1)
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_simple_kernel, 256, lds));
         else
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false>, trt::kPersistentBlock, lds));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false, false>, trt::kPersistentBlock, lds));
         *max_blocks_per_cu = blocks;
     }
     if (compute_units)

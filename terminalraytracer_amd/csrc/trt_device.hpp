@@ -92,6 +92,8 @@ struct FrameView
     const double *row_y;  // [height] -((row/H)*screen_height - screen_height/2)     (TRT.c:988), indexed by FRAME row
     double inv_spp;       // 1.0 / rays_per_pixel (TRT.c:1065)
     unsigned width_magic; // ceil(2^32 / width): pixel index -> row by multiply-high (persistent kernel)
+    unsigned spp_magic;   // ceil(2^32 / spp): sample-unit index -> pixel
+    double *samples;      // [pixels*spp][3] per-sample colours when the work units are samples
     double *out;          // compact framebuffer of the owned rows
     unsigned long long *counters; // [path, shadow] or nullptr
     unsigned int *queue;  // work-queue head for the persistent kernel

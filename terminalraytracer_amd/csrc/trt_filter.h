@@ -20,10 +20,14 @@
  * Every ray the renderer traces has been normalised (TRT.c:1008, :1055, :904, :933), so
  * a = 1 +- a few ulp.  The filter therefore evaluates with a := 1 and b' := 0,
  *
- *      pass  <=>  !( fma(cd,cd, C.W - kk) < thr )  &&  !( cd < cd_min ),    cd = C.d (FP32), W = 2 O'
+ *      m = fma(cd,cd, C.W - thr) - kk,   n = cd - cd_min,     cd = C.d (FP32), W = 2 O'
+ *      reject  <=>  m < 0  or  n < 0     (taken from the SIGN BITS of m and n: on gfx950 a compare
+ *                                         costs as much as three VOP2 operations, a subtract does not)
  *
- * and a ray with |a - 1| > 2^-40 (a degenerate, un-normalisable direction) simply passes every
- * sphere on to the exact test.  Per ray the set-up is 19 FP64 add/mul (no division, no sqrt),
+ * and a ray that is not "ok" -- |a - 1| > 2^-40 (a degenerate, un-normalisable direction), or bounds
+ * that overflowed FP32 -- passes every sphere on to the exact test; for an ok ray no intermediate
+ * can overflow (each is bounded by (Cn+Wn+Rm)^2, whose finiteness is part of ok), so m and n are
+ * never NaN.  Per ray the set-up is 19 FP64 add/mul (no division, no sqrt),
  * 8 conversions and a dozen FP32 ops; per sphere 7 FP32 FMA/mul and 2 compares on a
  * scalar-loaded table {Cx,Cy,Cz,kk}.
  *
@@ -31,14 +35,14 @@
  * FP32 evaluation PLUS the reference's own FP64 rounding PLUS the a := 1 approximation
  * (eps = 2^-24, u = 2^-53; Cn >= max|C|, Rm >= max r, Wn = |W|_1 >= |W|, On = |O|_1 >= |O|):
  *
- *      FP32 evaluation:   <= eps (20 Cn^2 + 8 Cn Wn + 6 Rm^2 + Wn^2/2)  <=  20 eps (Cn + Wn + Rm)^2
+ *      FP32 evaluation:   <= eps (20 Cn^2 + 8 Cn Wn + 6 Rm^2 + 2 Wn^2)   <=  20 eps (Cn + Wn + Rm)^2
+ *                         (thr = |O'|^2 - E <= Wn^2/4 rides through the C.W chain: 5 roundings of it)
  *      a := 1, b' := 0:   <= 2^-39 (On + Cn)^2  =  2^14 u (On + Cn)^2
  *      FP64 (set-up, and the reference's own disc):  <= 64 u (On + Cn + Rm)^2
  *      E  = 40 eps (Cn + Wn + Rm)^2 + 2^16 u (On + Cn + Rm)^2          (>= 2x head-room on each)
  *      Eb = 32 eps (Cn + |O.d|) + 2^16 u (On + Cn + Rm)
  *
- * Every comparison is written so that NaN/inf PASS the sphere on to the exact test.  The
- * second condition uses: b = 2 (o-c).d >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0  =>  miss.
+ * The second condition uses: b = 2 (o-c).d >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0  =>  miss.
  */
 #ifndef TRT_FILTER_H
 #define TRT_FILTER_H
@@ -52,10 +56,11 @@
 
 typedef struct
 {
-    float dx, dy, dz; /* dh */
-    float wx, wy, wz; /* W */
-    float thr;        /* reject if fma(cd,cd,cwk) < thr */
-    float cd_min;     /* reject if cd < cd_min */
+    float dx, dy, dz; /* d */
+    float wx, wy, wz; /* W = 2 O' */
+    float neg_thr;    /* -(|O'|^2 - E): start value of the C.W chain */
+    float cd_min;     /* O.d - Eb */
+    int ok;           /* 0: pass every sphere (degenerate ray or overflowed bounds) */
 } trt_ray_filter;
 
 /* per-scene constants of the culling table */
@@ -135,16 +140,28 @@ TRT_HD void trt_filter_setup(trt_ray_filter *f, double ox, double oy, double oz,
     const float Eb = 32.0f * TRT_EPS32 * (cn + __builtin_fabsf(odf)) + 65536.0f * TRT_U64F * m64;
     const int unit_ray = __builtin_fabs(a - 1.0) <= 9.094947017729282e-13; /* 2^-40; false for NaN */
     /* thr is pushed down by the rounding of kc itself and of the subtraction */
-    f->thr = unit_ray ? kc - E - 4.0f * TRT_EPS32 * kc : -__builtin_inff();
-    f->cd_min = unit_ray ? odf - Eb : -__builtin_inff();
+    f->neg_thr = -(kc - E - 4.0f * TRT_EPS32 * kc);
+    f->cd_min = odf - Eb;
+    f->ok = unit_ray && E < __builtin_inff() && Eb < __builtin_inff() && __builtin_fabsf(f->neg_thr) < __builtin_inff() &&
+            __builtin_fabsf(f->cd_min) < __builtin_inff();
+}
+
+/* sign word of one sphere for an ok ray: bit 31 set = reject */
+TRT_HD unsigned trt_filter_sign(const trt_ray_filter *f, float cx, float cy, float cz, float kk)
+{
+    const float cd = __builtin_fmaf(cz, f->dz, __builtin_fmaf(cy, f->dy, cx * f->dx));
+    const float n = cd - f->cd_min;
+    const float cw = __builtin_fmaf(cz, f->wz, __builtin_fmaf(cy, f->wy, __builtin_fmaf(cx, f->wx, f->neg_thr)));
+    const float m = __builtin_fmaf(cd, cd, cw) - kk;
+    unsigned mb, nb;
+    __builtin_memcpy(&mb, &m, 4);
+    __builtin_memcpy(&nb, &n, 4);
+    return mb | nb;
 }
 
 TRT_HD int trt_filter_pass(const trt_ray_filter *f, float cx, float cy, float cz, float kk)
 {
-    const float cd = __builtin_fmaf(cz, f->dz, __builtin_fmaf(cy, f->dy, cx * f->dx));
-    const float cwk = __builtin_fmaf(cz, f->wz, __builtin_fmaf(cy, f->wy, __builtin_fmaf(cx, f->wx, -kk)));
-    const float lhs = __builtin_fmaf(cd, cd, cwk);
-    return !(lhs < f->thr) && !(cd < f->cd_min);
+    return !f->ok || !(trt_filter_sign(f, cx, cy, cz, kk) >> 31);
 }
 
 #endif

@@ -39,6 +39,40 @@ namespace trt
 {
 
 constexpr int kPersistentBlock = 256;
+// TRT_DUP: cost-attribution diagnostic builds.  One stage is executed TWICE (the second result is merged so
+// that nothing can be optimised away, and it is identical, so the frame stays correct); the slowdown against
+// the normal build is that stage's cost.  1 = filter set-up, 2 = phase-1 sweep, 4 = plane test, 8 = NORM stage, 16 = phase-2 exact tests
+// (idempotent: strict '<' keeps the first result).
+#ifndef TRT_DUP
+#define TRT_DUP 0
+#endif
+// TRT_STAMP=1: diagnostic build with s_memtime stamps between the stages of the main loop; per-stage wave-cycle
+// sums go to counters[4..11] (read SHARES from it, never its run time: the stamps fence the schedule).
+#ifndef TRT_STAMP
+#define TRT_STAMP 0
+#endif
+#if TRT_STAMP
+#define TRT_STAMP_AT(slot)                                                                   \
+    do                                                                                       \
+    {                                                                                        \
+        unsigned long long now_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        stamp_sum[slot] += now_ - stamp_prev;                                                \
+        stamp_prev = now_;                                                                   \
+    } while (0)
+#else
+#define TRT_STAMP_AT(slot) \
+    do                     \
+    {                      \
+    } while (0)
+#endif
+#ifndef TRT_PERSISTENT_WAVES
+#define TRT_PERSISTENT_WAVES 4 // min waves per SIMD the register allocator must leave room for (= 256-thread blocks per CU)
+#endif
+constexpr unsigned kQueueChunkPixels = 64;   // work units fetched from the global queue per atomic (one wave's worth)
+constexpr unsigned kQueueChunkSamples = 256;
 constexpr int kCullGroup = 8;  // culling-table entries fetched per scalar-load batch (table padded to this)
 
 struct PersistentLaunch
@@ -80,8 +114,13 @@ enum : int
     kModePath = 0   // 1 + i: shadow ray of light i (directional lights first, then point lights)
 };
 
-template <bool COUNT>
-__global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(SceneView s, CullView cull, FrameView f)
+// SAMPLE_UNITS = false: a work unit is a PIXEL; the lane keeps the running mean and writes the pixel itself.
+// SAMPLE_UNITS = true : a work unit is ONE SAMPLE of a pixel (unit = pixel*spp + k); the lane writes the sample's
+//   normalised colour (TRT.c:1061) to f.samples[unit] and reduce_samples_kernel forms the mean in the reference's
+//   order (TRT.c:1063-1065).  Ten times finer balancing: chosen by the host when there are few pixels per lane
+//   (small frames, or one frame sharded over several GPUs).
+template <bool COUNT, bool SAMPLE_UNITS>
+__global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render_persistent_kernel(SceneView s, CullView cull, FrameView f)
 {
     extern __shared__ double lds[];
     const int n = s.num_spheres, nd = s.num_dir, np = s.num_point, nl = nd + np;
@@ -125,7 +164,8 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const unsigned total = (unsigned)f.local_rows * (unsigned)f.width; // < 2^31, checked by the host
+    // number of work units; < 2^31, checked by the host
+    const unsigned total = (unsigned)f.local_rows * (unsigned)f.width * (SAMPLE_UNITS ? (unsigned)f.spp : 1u);
     const d3 gp = load3(s.ground), gn = load3(s.ground + 3);
     const const_float_ptr table = (const_float_ptr)(uintptr_t)cull.table;
 
@@ -146,9 +186,15 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
     int h_mat = 0; // index into l_mat (sphere i, n = ground even, n+1 = ground odd)
     double light_d2 = 0.0, strength = 0.0;
     unsigned n_path = 0, n_shadow = 0, n_trips = 0, n_phase2 = 0;
+    unsigned pool_next = 0, pool_end = 0; // wave-uniform: units [pool_next, pool_end) fetched from the queue, not yet handed out
 
+#if TRT_STAMP
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     while (__any(alive))
     {
+        TRT_STAMP_AT(7); // loop back-edge / exit test
         if (COUNT)
             n_trips++;
         // =================================== TRACE (TRT.c:793-856) ===================================
@@ -168,35 +214,71 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
 
         trt_ray_filter flt;
         trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
+        if (TRT_DUP & 1)
+        {
+            d3 o2 = o, d2 = d;
+            asm volatile("" : "+v"(o2.x), "+v"(o2.y), "+v"(o2.z), "+v"(d2.x), "+v"(d2.y), "+v"(d2.z));
+            trt_ray_filter f2;
+            trt_filter_setup(&f2, o2.x, o2.y, o2.z, d2.x, d2.y, d2.z, dot(d2, d2), cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
+            if (f2.neg_thr != flt.neg_thr || f2.cd_min != flt.cd_min)
+                flt.ok = 0; // never taken
+        }
 
+        TRT_STAMP_AT(0); // filter set-up
         for (int base = 0; base < cull.padded; base += 64)
         {
-            // phase 1: uniform sweep of up to 64 table entries, scalar-loaded
-            unsigned long long cand = 0;
+            // phase 1: uniform sweep of up to 64 table entries, scalar-loaded.  Each test leaves its verdict in a
+            // sign bit that v_alignbit shifts into a per-lane word: sphere base+j ends up at bit 63-j of `cand`.
             const int chunk = (cull.padded - base) < 64 ? (cull.padded - base) : 64;
-            for (int g = 0; g < chunk; g += kCullGroup)
+            unsigned word[2] = {~0u, ~0u}; // all "reject" until shifted in
+            unsigned word_dup = 0;
+            for (int rep = 0; rep < ((TRT_DUP & 2) ? 2 : 1); rep++)
             {
-                unsigned bits = 0;
+            if (TRT_DUP & 2)
+                asm volatile("" : "+v"(flt.dx), "+v"(flt.wx), "+v"(flt.neg_thr));
 #pragma unroll
-                for (int j = 0; j < kCullGroup; j++)
+            for (int h = 0; h < 2; h++)
+            {
+                const int first = base + 32 * h, count = (chunk - 32 * h) < 32 ? (chunk - 32 * h) : 32;
+                unsigned bits = ~0u;
+                for (int g = 0; g < count; g += kCullGroup)
                 {
-                    const const_float_ptr e = table + (long)(base + g + j) * 4;
-                    if (trt_filter_pass(&flt, e[0], e[1], e[2], e[3]))
-                        bits |= 1u << j;
+#pragma unroll
+                    for (int j = 0; j < kCullGroup; j++)
+                    {
+                        const const_float_ptr e = table + (long)(first + g + j) * 4;
+                        bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign(&flt, e[0], e[1], e[2], e[3]), 31);
+                    }
                 }
-                cand |= (unsigned long long)bits << g;
+                // the first sphere of this half must sit at bit 31: shift out the `32 - count` untouched bits
+                if (rep == 1)
+                    word_dup |= bits ^ ~word[h]; // identical sweep: contributes nothing
+                word[h] = count > 0 ? ~(bits << (32 - count)) & (count == 32 ? ~0u : ~((1u << (32 - count)) - 1u)) : 0u;
             }
+            }
+            if ((TRT_DUP & 2) && word_dup == 0x12345u)
+                word[0] = 0; // never taken
+            unsigned long long cand = ((unsigned long long)word[0] << 32) | word[1];
+            if (!flt.ok)
+                cand = chunk == 64 ? ~0ull : ~((1ull << (64 - chunk)) - 1ull); // degenerate ray: every sphere of the chunk
             if (!has_ray)
                 cand = 0;
+            TRT_STAMP_AT(1); // phase 1
             // phase 2: exact FP64 tests of this lane's candidates, ascending index (first index wins ties)
+            const unsigned long long cand_again = cand;
+            for (int rep2 = 0; rep2 < ((TRT_DUP & 16) ? 2 : 1); rep2++)
+            {
+            if (rep2 == 1)
+                cand = cand_again;
             while (__any(cand != 0))
             {
                 if (COUNT)
                     n_phase2++;
                 if (cand != 0)
                 {
-                    const int i = base + __builtin_ctzll(cand);
-                    cand &= cand - 1;
+                    const int lead = __builtin_clzll(cand); // highest bit = lowest sphere index
+                    const int i = base + lead;
+                    cand &= ~(0x8000000000000000ull >> lead);
                     if (i < n)
                     {
                         const d3 c = d3{l_cx[i], l_cy[i], l_cz[i]};
@@ -224,6 +306,8 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
                     }
                 }
             }
+            }
+            TRT_STAMP_AT(2); // phase 2
         }
         // ground plane (TRT.c:831-853)
         if (has_ray && !(any_hit_suffices && best_i >= 0))
@@ -239,6 +323,17 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
                     best_i = n;
                 }
             }
+        }
+
+        TRT_STAMP_AT(3); // plane
+        if (TRT_DUP & 4)
+        {
+            d3 o2 = o, d2 = d;
+            asm volatile("" : "+v"(o2.x), "+v"(o2.y), "+v"(o2.z), "+v"(d2.x), "+v"(d2.y), "+v"(d2.z));
+            d3 p;
+            if (has_ray && !(any_hit_suffices && best_i >= 0) && hit_plane(o2, d2, gp, gn, p))
+                if (dist2(o2, p) < best_d2)
+                    best_i = n; // never changes anything: the first test already took it
         }
 
         // =================================== POST ===================================
@@ -321,31 +416,66 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
             qn = 1.0;
             qd = weight_sum_new; // TRT.c:1061
             k_next = k + 1;
-            if (k_next == f.spp)
+            if (SAMPLE_UNITS || k_next == f.spp)
             {
-                end_pixel = true;
+                end_pixel = true; // the unit (pixel, or single sample) is finished
                 k_next = 0;
             }
         }
         want_pixel = alive && (end_pixel || mode == kModeBoot);
-        unsigned pix_next = pix;
+        unsigned pix_next = pix; // index of the lane's work unit
         double sx_next = sx_base, sy_next = sy_base;
         {
             const unsigned long long need = __ballot(want_pixel);
             if (need)
-            { // wave-aggregated pull from the pixel queue
-                unsigned first = 0;
-                const int leader = __builtin_ctzll(need);
-                if (lane == leader)
-                    first = atomicAdd(f.queue, (unsigned)__builtin_popcountll(need));
-                first = __shfl(first, leader);
+            { // serve the lanes from the wave's pool; refill the pool with ONE atomic per kQueueChunk units
+                const unsigned wanted = (unsigned)__builtin_popcountll(need);
+                unsigned first = pool_next; // wave-uniform
+                if (pool_end - pool_next < wanted)
+                { // not enough left: fetch a fresh chunk (what is left of the old one is served first)
+                    const unsigned left = pool_end - pool_next;
+                    const unsigned chunk = SAMPLE_UNITS ? kQueueChunkSamples : kQueueChunkPixels;
+                    unsigned fresh = 0;
+                    const int leader = __builtin_ctzll(need);
+                    if (lane == leader)
+                        fresh = atomicAdd(f.queue, chunk);
+                    fresh = __shfl(fresh, leader);
+                    // lanes ranked < left take the old units, the others the first units of the new chunk
+                    const unsigned rank = (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+                    if (want_pixel)
+                        pix_next = rank < left ? pool_next + rank : fresh + (rank - left);
+                    pool_next = fresh + (wanted - left);
+                    pool_end = fresh + chunk;
+                    first = 0xffffffffu; // marks "already assigned"
+                }
+                else
+                    pool_next += wanted;
                 if (want_pixel)
                 {
-                    pix_next = first + (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+                    if (first != 0xffffffffu)
+                        pix_next = first + (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull));
                     if (pix_next < total)
-                    { // row = pix / width by multiply-high with min(ceil(2^32/width), 2^32-1): off by at most one
-                        unsigned row = __umulhi(pix_next, f.width_magic);
-                        int col = (int)(pix_next - row * (unsigned)f.width);
+                    {
+                        unsigned pixel = pix_next;
+                        if (SAMPLE_UNITS)
+                        { // unit -> (pixel, k) by multiply-high with min(ceil(2^32/spp), 2^32-1): off by at most one
+                            pixel = __umulhi(pix_next, f.spp_magic);
+                            int kk = (int)(pix_next - pixel * (unsigned)f.spp);
+                            if (kk < 0)
+                            {
+                                pixel--;
+                                kk += f.spp;
+                            }
+                            else if (kk >= f.spp)
+                            {
+                                pixel++;
+                                kk -= f.spp;
+                            }
+                            k_next = kk;
+                        }
+                        // row = pixel / width the same way
+                        unsigned row = __umulhi(pixel, f.width_magic);
+                        int col = (int)(pixel - row * (unsigned)f.width);
                         if (col < 0)
                         {
                             row--;
@@ -375,6 +505,7 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
             needB = true;
         }
 
+        TRT_STAMP_AT(4); // POST
         // =================================== NORM (convergent) ===================================
         d3 nA = uA, nB = uB;
         double q = 0.0;
@@ -384,7 +515,24 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
             nB = unit(uB);
         if (__any(end_sample || (shadow_back && needB)))
             q = qn / qd;
+        if (TRT_DUP & 8)
+        { // same work again on opaque copies of the inputs
+            d3 vA = uA, vB = uB;
+            double vn = qn, vd = qd;
+            asm volatile("" : "+v"(vA.x), "+v"(vA.y), "+v"(vA.z), "+v"(vB.x), "+v"(vB.y), "+v"(vB.z), "+v"(vn), "+v"(vd));
+            d3 mA = vA, mB = vB;
+            double q2 = 0.0;
+            if (__any(needA))
+                mA = unit(vA);
+            if (__any(needB))
+                mB = unit(vB);
+            if (__any(end_sample || (shadow_back && needB)))
+                q2 = vn / vd;
+            if (mA.x != nA.x || mB.y != nB.y || q2 != q)
+                nA.z = mA.z; // never taken: identical by construction
+        }
 
+        TRT_STAMP_AT(5); // NORM
         // =================================== FINISH ===================================
         if (path_hit)
         {
@@ -472,15 +620,25 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
         if (end_sample)
         { // TRT.c:1061-1066
             sample = scale(sample, q);
-            mean = add(mean, sample);
-            if (end_pixel)
+            if (SAMPLE_UNITS)
             {
-                mean = scale(mean, f.inv_spp);
-                double *out = f.out + (size_t)pix * 3;
-                out[0] = mean.x;
-                out[1] = mean.y;
-                out[2] = mean.z;
-                mean = d3{0.0, 0.0, 0.0};
+                double *out = f.samples + (size_t)pix * 3;
+                out[0] = sample.x;
+                out[1] = sample.y;
+                out[2] = sample.z;
+            }
+            else
+            {
+                mean = add(mean, sample);
+                if (end_pixel)
+                {
+                    mean = scale(mean, f.inv_spp);
+                    double *out = f.out + (size_t)pix * 3;
+                    out[0] = mean.x;
+                    out[1] = mean.y;
+                    out[2] = mean.z;
+                    mean = d3{0.0, 0.0, 0.0};
+                }
             }
         }
         if (end_sample || mode == kModeBoot)
@@ -506,6 +664,7 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
                 has_ray = false;
             }
         }
+        TRT_STAMP_AT(6); // FINISH
     }
 
     if (COUNT && f.counters)
@@ -516,8 +675,27 @@ __global__ __launch_bounds__(kPersistentBlock) void render_persistent_kernel(Sce
         { // diagnostics: loop trips and phase-2 rounds per wave (lane utilisation = traces / (64 * trips))
             atomicAdd(&f.counters[2], (unsigned long long)n_trips);
             atomicAdd(&f.counters[3], (unsigned long long)n_phase2);
+#if TRT_STAMP
+            for (int i = 0; i < 8; i++)
+                atomicAdd(&f.counters[4 + i], stamp_sum[i]);
+#endif
         }
     }
+}
+
+// TRT.c:1063-1066 for SAMPLE_UNITS frames: pixel = ((0 + s0) + s1 + ... ) * (1/spp), samples in index order
+__global__ __launch_bounds__(256) void reduce_samples_kernel(const double *samples, double *out, long values, int spp, double inv_spp)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; // one thread per colour channel of a pixel
+    if (i >= values)
+        return;
+    const long pixel = i / 3;
+    const int channel = (int)(i - pixel * 3);
+    const double *src = samples + pixel * spp * 3 + channel;
+    double mean = 0.0;
+    for (int k = 0; k < spp; k++)
+        mean += src[k * 3];
+    out[i] = mean * inv_spp;
 }
 
 } // namespace trt

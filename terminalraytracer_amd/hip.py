@@ -14,7 +14,8 @@ import numpy as np
 from . import layout as L
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrt_hip.so")
+# TRT_HIP_LIB selects another build of the same library (kernel-tuning A/B runs); default is the in-tree one
+LIB_PATH = os.environ.get("TRT_HIP_LIB") or os.path.join(_HERE, "libtrt_hip.so")
 
 TRT_OK = 0
 ERRORS = {-1: "TRT_ERR_HIP", -2: "TRT_ERR_ARGUMENT", -3: "TRT_ERR_NO_SCENE", -4: "TRT_ERR_CAPACITY",
@@ -65,6 +66,7 @@ SYMBOLS = {
     "trt_read_counters": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "trt_read_diagnostics": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "trt_set_kernel": (_I, [_VP, _I]),
+    "trt_set_work_units": (_I, [_VP, _I]),
     "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
     "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
     "trt_probe_rays": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
@@ -141,6 +143,10 @@ class Context:
 
     def set_kernel(self, which):
         _check(lib().trt_set_kernel(self._h, which))
+
+    def set_work_units(self, units):
+        """0 automatic, 1 pixels, 2 samples (trt_set_work_units)"""
+        _check(lib().trt_set_work_units(self._h, units))
 
     def render_device(self, camera_array, rows, bounce_limit, rays_per_pixel, device_ptr, capacity_bytes):
         cam = camera_struct(camera_array)

@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 
 SMALL = T.golden_cases(("small", "medium"))
 LARGE = T.golden_cases(("large",))
-KERNELS = [hip.Context.PRODUCTION, hip.Context.REFERENCE_ORDER]
+# (kernel, work units): production kernel with pixels / samples as work units, and the reference-order kernel
+KERNELS = [(hip.Context.PRODUCTION, 1), (hip.Context.PRODUCTION, 2), (hip.Context.REFERENCE_ORDER, 0)]
+KERNEL_IDS = ["production_pixel_units", "production_sample_units", "reference_order"]
 
 
 @pytest.fixture(scope="module")
@@ -30,8 +32,9 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint64)
 
 
-def render(ctx, scene, w, h, b, s, kernel=hip.Context.PRODUCTION, rows=None):
-    ctx.set_kernel(kernel)
+def render(ctx, scene, w, h, b, s, kernel=(hip.Context.PRODUCTION, 0), rows=None):
+    ctx.set_kernel(kernel[0])
+    ctx.set_work_units(kernel[1])
     ctx.set_scene(scene)
     return ctx.render_host(scene.camera, rows or hip.RowSet.whole(w, h), b, s)
 
@@ -64,7 +67,7 @@ def test_single_rays_match_reference_vectors(ctx):
     assert np.array_equal(bits(lit[hit]), bits(d["lit"][hit]))
 
 
-@pytest.mark.parametrize("kernel", KERNELS, ids=["production", "reference_order"])
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("case", SMALL, ids=[c["name"] for c in SMALL])
 def test_frame_matches_reference_golden(ctx, case, kernel):
     scene = T.golden_scene(case)
@@ -115,16 +118,19 @@ def test_north_star_config_production_equals_reference_order_and_oracle(ctx):
     """BASELINE config 3 at full size: 1920x1080, 64 spheres, 8 bounces, 10 rays per pixel."""
     w, h = 1920, 1080
     scene = S.synth_scene(64, S.synth_sky(256), T.bench_camera(w, h), seed=1234)
-    fast = render(ctx, scene, w, h, 8, 10, hip.Context.PRODUCTION)
-    slow = render(ctx, scene, w, h, 8, 10, hip.Context.REFERENCE_ORDER)
+    fast = render(ctx, scene, w, h, 8, 10, KERNELS[0])
+    fast2 = render(ctx, scene, w, h, 8, 10, KERNELS[1])
+    slow = render(ctx, scene, w, h, 8, 10, KERNELS[2])
     assert np.array_equal(bits(fast), bits(slow))
+    assert np.array_equal(bits(fast2), bits(slow))
     band, _ = T.oracle_render(scene, w, h, 8, 10, rows=(530, 562))  # rows through the sphere field
     assert np.array_equal(bits(fast[530:562]), bits(band))
     assert np.isfinite(fast).all() and fast.min() >= 0.0 and fast.max() <= 1.0
 
 
+@pytest.mark.parametrize("units", [1, 2], ids=["pixel_units", "sample_units"])
 @pytest.mark.parametrize("world,tile", [(2, 8), (8, 8), (3, 5)])
-def test_row_tile_shards_reassemble_to_the_whole_frame(ctx, world, tile):
+def test_row_tile_shards_reassemble_to_the_whole_frame(ctx, world, tile, units):
     case = next(c for c in SMALL if c["name"] == "synth64_128x72_b8")
     scene = T.golden_scene(case)
     w, h = 128, 72
@@ -132,7 +138,7 @@ def test_row_tile_shards_reassemble_to_the_whole_frame(ctx, world, tile):
     out = np.zeros_like(whole)
     for rank in range(world):
         rs = hip.RowSet.shard(w, h, rank, world, tile)
-        part = render(ctx, scene, w, h, 8, 10, rows=rs)
+        part = render(ctx, scene, w, h, 8, 10, (hip.Context.PRODUCTION, units), rows=rs)
         for i in range(part.shape[0]):
             out[hip.lib().trt_rowset_frame_row(C.byref(rs), i)] = part[i]
     assert np.array_equal(bits(out), bits(whole))
@@ -144,6 +150,7 @@ def test_device_resident_render_and_rgb8_quantisation(ctx):
     case = next(c for c in SMALL if c["name"] == "demo_160x48_b4")
     scene = T.golden_scene(case)
     ctx.set_kernel(hip.Context.PRODUCTION)
+    ctx.set_work_units(0)
     ctx.set_scene(scene)
     fb = torch.zeros(48 * 160 * 3, dtype=torch.float64, device="cuda:0")
     rgb = torch.zeros(48 * 160 * 3, dtype=torch.uint8, device="cuda:0")

@@ -52,6 +52,12 @@
 #define X_OR3(i) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
 #define X_ADDC(i) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(a##i)::"vcc");
 #define X_CVT(i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a##i) : "v"(bd));
+#define X_PKFMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p##i) : "v"(pc), "v"(pb));
+#define X_PKMUL(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p##i) : "v"(pc));
+#define X_ALIGN(i) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a##i) : "v"(b));
+#define X_SUB32(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define X_CNDS(i) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a##i) : "v"(b));
+#define X_MFMA(i) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(m##i) : "v"(fa), "v"(fb));
 #define X_RDL(i) asm volatile("v_readlane_b32 s20, %0, 3" ::"v"(a##i) : "s20");
 
 KERNEL(fma_f64, D64, REP8(X_FMA64), S64)
@@ -73,6 +79,19 @@ KERNEL(mov_b32, DI, REP8(X_MOV), SI)
 KERNEL(or3_b32, DI, REP8(X_OR3), SI)
 KERNEL(addc_u32, DI, REP8(X_ADDC), SI)
 KERNEL(readlane, DI, REP8(X_RDL), SI)
+KERNEL(alignbit, DI, REP8(X_ALIGN), SI)
+KERNEL(sub_f32, D32, REP8(X_SUB32), S32)
+KERNEL(cndmask_sgpr, DI, REP8(X_CNDS), SI)
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+#define DPK f2 p0 = {(float)seed, 1.f}, p1 = p0 + 1.f, p2 = p0 + 2.f, p3 = p0 + 3.f, p4 = p0 + 4.f, p5 = p0 + 5.f, p6 = p0 + 6.f, p7 = p0 + 7.f, pb = p0 * 0.5f, pc = {1.0000001f, 0.9999999f};
+#define SPK if (p0.x + p1.x + p2.x + p3.x + p4.y + p5.y + p6.y + p7.y == 12345.678f) out[0] = 1;
+KERNEL(pk_fma_f32, DPK, REP8(X_PKFMA), SPK)
+KERNEL(pk_mul_f32, DPK, REP8(X_PKMUL), SPK)
+#define DMF f16v m0 = {}, m1 = {}, m2 = {}, m3 = {}; float fa = (float)seed, fb = fa * 0.5f;
+#define SMF if (m0[0] + m1[1] + m2[2] + m3[3] == 12345.678f) out[0] = 1;
+#define REP4(x) x(0) x(1) x(2) x(3)
+KERNEL(mfma_32x32x2_f32, DMF, REP4(X_MFMA) REP4(X_MFMA), SMF)
 __global__ void k_cvt_f32_f64(unsigned long long *out, double seed)
 {
     float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
@@ -104,7 +123,7 @@ int main()
                     {"v_div_fixup_f64", k_div_fixup_f64}, {"v_ldexp_f64", k_ldexp_f64}, {"v_cmp_lt_f64", k_cmp_f64},
                     {"v_cvt_f32_f64", k_cvt_f32_f64}, {"v_fma_f32", k_fma_f32}, {"v_fmac_f32", k_fmac_f32},
                     {"v_cmp_lt_f32 vcc", k_cmp_f32_vcc}, {"v_cmp_lt_f32 sgpr", k_cmp_f32_sgpr}, {"v_cndmask_b32", k_cndmask_b32},
-                    {"v_mov_b32", k_mov_b32}, {"v_or3_b32", k_or3_b32}, {"v_addc_co_u32", k_addc_u32}, {"v_readlane_b32", k_readlane}};
+                    {"v_mov_b32", k_mov_b32}, {"v_or3_b32", k_or3_b32}, {"v_addc_co_u32", k_addc_u32}, {"v_readlane_b32", k_readlane}, {"v_alignbit_b32", k_alignbit}, {"v_sub_f32", k_sub_f32}, {"v_cndmask_b32 sgpr", k_cndmask_sgpr}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_mfma_f32_32x32x2", k_mfma_32x32x2_f32}};
     unsigned long long *d;
     hipMalloc(&d, 1 << 20);
     printf("%-20s %10s %10s %10s %10s   (cycles per wave-instruction per SIMD = wave cycles / instrs * waves... see columns)\n", "instruction",
