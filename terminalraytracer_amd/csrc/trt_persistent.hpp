@@ -68,6 +68,12 @@ constexpr int kPersistentBlock = 256;
     {                      \
     } while (0)
 #endif
+// TRT_SWEEP_LDS: where phase 1 reads the culling table from.  1 (default) = from LDS, one broadcast ds_read_b128
+// per sphere, so that every VALU operand is a VGPR; 0 = scalar loads, coefficients as SGPR operands.  On gfx950 an
+// SGPR source roughly doubles the issue cost of v_fmac/v_mul/v_fma (tools/ubench_valu.hip), 25.7 vs ~16 cycles per test.
+#ifndef TRT_SWEEP_LDS
+#define TRT_SWEEP_LDS 1
+#endif
 #ifndef TRT_PERSISTENT_WAVES
 #define TRT_PERSISTENT_WAVES 4 // min waves per SIMD the register allocator must leave room for (= 256-thread blocks per CU)
 #endif
@@ -93,8 +99,10 @@ inline PersistentLaunch persistent_launch_shape(int compute_units, int blocks_pe
 constexpr int kLdsCameraDoubles = 13;
 inline size_t persistent_lds_bytes(const SceneView &s, int spp)
 {
+    const size_t padded = ((size_t)s.num_spheres + kCullGroup - 1) / kCullGroup * kCullGroup;
     return sizeof(double) * ((size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * 6 +
-                             (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp);
+                             (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp +
+                             (TRT_SWEEP_LDS ? padded * 2 : 0) /* culling table first: 4 floats per sphere, 16-B aligned */);
 }
 
 struct CullView
@@ -122,9 +130,10 @@ enum : int
 template <bool COUNT, bool SAMPLE_UNITS>
 __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render_persistent_kernel(SceneView s, CullView cull, FrameView f)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = s.num_spheres, nd = s.num_dir, np = s.num_point, nl = nd + np;
-    double *const l_cx = lds, *const l_cy = l_cx + n, *const l_cz = l_cy + n, *const l_r2 = l_cz + n;
+    float4 *const l_cull = (float4 *)lds; // culling table image, read with broadcast ds_read_b128
+    double *const l_cx = lds + (TRT_SWEEP_LDS ? cull.padded * 2 : 0), *const l_cy = l_cx + n, *const l_cz = l_cy + n, *const l_r2 = l_cz + n;
     double *const l_mat = l_r2 + n;
     double *const l_dir = l_mat + (n + 2) * 5;
     double *const l_pt = l_dir + nd * 6;
@@ -161,6 +170,9 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
         l_cam[12] = -f.cam[12]; // TRT.c:989
     for (int i = threadIdx.x; i < 2 * f.spp; i += blockDim.x)
         l_jit[i] = f.jitter[i];
+    if (TRT_SWEEP_LDS)
+        for (int i = threadIdx.x; i < cull.padded; i += blockDim.x)
+            l_cull[i] = ((const float4 *)cull.table)[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -246,8 +258,16 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
 #pragma unroll
                     for (int j = 0; j < kCullGroup; j++)
                     {
-                        const const_float_ptr e = table + (long)(first + g + j) * 4;
-                        bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign(&flt, e[0], e[1], e[2], e[3]), 31);
+                        if (TRT_SWEEP_LDS)
+                        {
+                            const float4 e = l_cull[first + g + j]; // same address in every lane: LDS broadcast
+                            bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign(&flt, e.x, e.y, e.z, e.w), 31);
+                        }
+                        else
+                        {
+                            const const_float_ptr e = table + (long)(first + g + j) * 4;
+                            bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign(&flt, e[0], e[1], e[2], e[3]), 31);
+                        }
                     }
                 }
                 // the first sphere of this half must sit at bit 31: shift out the `32 - count` untouched bits

@@ -58,6 +58,13 @@
 #define X_SUB32(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a##i) : "v"(b));
 #define X_CNDS(i) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a##i) : "v"(b));
 #define X_MFMA(i) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(m##i) : "v"(fa), "v"(fb));
+#define X_FMACS(i) asm volatile("v_fmac_f32 %0, s20, %1" : "+v"(a##i) : "v"(b) : "s20");
+#define X_FMACS2(i) asm volatile("v_fmac_f32 %0, s2%1, %2" : "+v"(a##i) : "n"(i), "v"(b));
+#define X_MULS(i) asm volatile("v_mul_f32 %0, s20, %1" : "=v"(a##i) : "v"(b));
+#define X_FMAS(i) asm volatile("v_fma_f32 %0, s20, %1, -%2" : "=v"(a##i) : "v"(b), "v"(c));
+#define X_SUBREVS(i) asm volatile("v_subrev_f32 %0, s20, %0" : "+v"(a##i));
+#define X_OR(i) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+#define X_CHAIN(i) asm volatile("v_mul_f32 %0, s20, %2\n v_fma_f32 %1, s20, %3, -%4\n v_fmac_f32 %0, s21, %3\n v_fmac_f32 %1, s21, %4\n v_fmac_f32 %0, s22, %4\n v_fmac_f32 %1, s22, %2\n v_fmac_f32 %1, %0, %0\n v_sub_f32 %0, %0, %2\n v_subrev_f32 %1, s23, %1\n v_or_b32 %0, %0, %1\n v_alignbit_b32 %5, %5, %0, 31" : "=&v"(a##i), "=&v"(u##i), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
 #define X_RDL(i) asm volatile("v_readlane_b32 s20, %0, 3" ::"v"(a##i) : "s20");
 
 KERNEL(fma_f64, D64, REP8(X_FMA64), S64)
@@ -79,6 +86,15 @@ KERNEL(mov_b32, DI, REP8(X_MOV), SI)
 KERNEL(or3_b32, DI, REP8(X_OR3), SI)
 KERNEL(addc_u32, DI, REP8(X_ADDC), SI)
 KERNEL(readlane, DI, REP8(X_RDL), SI)
+KERNEL(fmac_f32_sgpr, D32, REP8(X_FMACS), S32)
+KERNEL(fmac_f32_sgpr_var, D32, REP8(X_FMACS2), S32)
+KERNEL(mul_f32_sgpr, D32, REP8(X_MULS), S32)
+KERNEL(fma_f32_sgpr, D32, REP8(X_FMAS), S32)
+KERNEL(subrev_f32_sgpr, D32, REP8(X_SUBREVS), S32)
+KERNEL(or_b32, DI, REP8(X_OR), SI)
+#define DCH float a0, a1, a2, a3, a4, a5, a6, a7, u0, u1, u2, u3, u4, u5, u6, u7, b = (float)seed, c = b + 1, d = b + 2; unsigned e = 0;
+#define SCH if (e == 12345u) out[0] = 1;
+KERNEL(sweep_chain_x11, DCH, REP8(X_CHAIN), SCH)
 KERNEL(alignbit, DI, REP8(X_ALIGN), SI)
 KERNEL(sub_f32, D32, REP8(X_SUB32), S32)
 KERNEL(cndmask_sgpr, DI, REP8(X_CNDS), SI)
@@ -123,7 +139,7 @@ int main()
                     {"v_div_fixup_f64", k_div_fixup_f64}, {"v_ldexp_f64", k_ldexp_f64}, {"v_cmp_lt_f64", k_cmp_f64},
                     {"v_cvt_f32_f64", k_cvt_f32_f64}, {"v_fma_f32", k_fma_f32}, {"v_fmac_f32", k_fmac_f32},
                     {"v_cmp_lt_f32 vcc", k_cmp_f32_vcc}, {"v_cmp_lt_f32 sgpr", k_cmp_f32_sgpr}, {"v_cndmask_b32", k_cndmask_b32},
-                    {"v_mov_b32", k_mov_b32}, {"v_or3_b32", k_or3_b32}, {"v_addc_co_u32", k_addc_u32}, {"v_readlane_b32", k_readlane}, {"v_alignbit_b32", k_alignbit}, {"v_sub_f32", k_sub_f32}, {"v_cndmask_b32 sgpr", k_cndmask_sgpr}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_mfma_f32_32x32x2", k_mfma_32x32x2_f32}};
+                    {"v_mov_b32", k_mov_b32}, {"v_or3_b32", k_or3_b32}, {"v_addc_co_u32", k_addc_u32}, {"v_readlane_b32", k_readlane}, {"v_fmac_f32 s,v", k_fmac_f32_sgpr}, {"v_fmac_f32 s2x,v", k_fmac_f32_sgpr_var}, {"v_mul_f32 s,v", k_mul_f32_sgpr}, {"v_fma_f32 s,v,-v", k_fma_f32_sgpr}, {"v_subrev_f32 s,v", k_subrev_f32_sgpr}, {"v_or_b32", k_or_b32}, {"sweep chain (11)", k_sweep_chain_x11}, {"v_alignbit_b32", k_alignbit}, {"v_sub_f32", k_sub_f32}, {"v_cndmask_b32 sgpr", k_cndmask_sgpr}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_mfma_f32_32x32x2", k_mfma_32x32x2_f32}};
     unsigned long long *d;
     hipMalloc(&d, 1 << 20);
     printf("%-20s %10s %10s %10s %10s   (cycles per wave-instruction per SIMD = wave cycles / instrs * waves... see columns)\n", "instruction",
