@@ -119,8 +119,9 @@ int trt_read_counters(trt_context *ctx, unsigned long long *path_rays, unsigned 
  * Lane utilisation of the trace loop = (path + shadow) / (64 * wave_loop_trips). */
 int trt_read_diagnostics(trt_context *ctx, unsigned long long *wave_loop_trips, unsigned long long *phase2_rounds);
 
-/* Kernel selection: 0 = production kernel; 1 = reference-order debugging kernel (one lane per
- * pixel, no culling).  Both are HIP; there is no CPU path. */
+/* Kernel selection: 0 = production kernel (persistent waves, mode-synchronous rounds); 1 = reference-order
+ * debugging kernel (one lane per pixel, no culling); 2 = the earlier production design (persistent waves,
+ * per-lane state machine), kept for A/B measurements.  All are HIP; there is no CPU path. */
 int trt_set_kernel(trt_context *ctx, int which);
 
 /* Work units of the production kernel: 0 = automatic (default), 1 = whole pixels (the lane keeps the running

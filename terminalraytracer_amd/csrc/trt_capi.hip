@@ -15,6 +15,7 @@
 
 #include "trt_device.hpp"
 #include "trt_persistent.hpp"
+#include "trt_rounds.hpp"
 #include "trt_simple.hpp"
 
 namespace
@@ -104,7 +105,8 @@ struct trt_context
     int axes_w = -1, axes_h = -1;
     double axes_sw = 0.0, axes_sh = 0.0;
 
-    int kernel = 0; // 0 production (persistent), 1 reference-order
+    int kernel = 0; // 0 production (synchronous rounds), 1 reference-order, 2 per-lane state machine
+    int rounds_blocks_per_cu = 0;
     int units = 0;  // work units of the production kernel: 0 automatic, 1 pixels, 2 samples
     bool counters_enabled = false;
     unsigned long long last_trips = 0, last_phase2 = 0; // diagnostics of the counting kernel variant
@@ -202,6 +204,9 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false, false>, trt::kPersistentBlock,
                                                          trt::persistent_lds_bytes(v, 64)));
     ctx->persistent_blocks_per_cu = std::max(blocks, 1);
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock,
+                                                         trt::persistent_lds_bytes(v, 64)));
+    ctx->rounds_blocks_per_cu = std::max(blocks, 1);
     return TRT_OK;
 }
 
@@ -311,6 +316,8 @@ extern "C" int trt_create(int device, trt_context **out)
     (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     *out = ctx;
     return TRT_OK;
 }
@@ -385,7 +392,7 @@ extern "C" int trt_read_diagnostics(trt_context *ctx, unsigned long long *wave_l
 
 extern "C" int trt_set_kernel(trt_context *ctx, int which)
 {
-    if (!ctx || which < 0 || which > 1)
+    if (!ctx || which < 0 || which > 2)
         return fail(TRT_ERR_ARGUMENT, "kernel %d", which);
     ctx->kernel = which;
     return TRT_OK;
@@ -419,7 +426,9 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
     ctx->last_phase2 = c[3];
     if (getenv("TRT_PRINT_STAMPS"))
     { // diagnostic builds only (-DTRT_STAMP=1): per-stage wave-cycle sums
-        static const char *const names[8] = {"filter set-up", "phase 1 sweep", "phase 2 exact", "plane", "POST", "NORM", "FINISH", "loop edge"};
+        static const char *const names_sm[8] = {"filter set-up", "phase 1 sweep", "phase 2 exact", "plane", "POST", "NORM", "FINISH", "loop edge"};
+        static const char *const names_rounds[8] = {"units+primary", "unit(next_dir)", "P trace", "P post", "S directional", "S point", "lit accumulate", "END+edge"};
+        const char *const *names = ctx->kernel == 0 && ctx->units != 1 ? names_rounds : names_sm;
         unsigned long long total = 0;
         for (int i = 0; i < 8; i++)
             total += c[4 + i];
@@ -495,9 +504,10 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
     else
     {
         HIP_TRY(hipMemsetAsync(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int), ctx->stream));
-        const long lanes = (long)ctx->compute_units * ctx->persistent_blocks_per_cu * trt::kPersistentBlock;
-        // pixels as work units need many of them per lane to balance (a pixel is 10..240 traces); otherwise samples
-        const bool sample_units = ctx->units == 2 || (ctx->units == 0 && pixels < 48 * lanes);
+        // production (kernel 0): synchronous rounds over sample units; pixel units on request go to the state machine
+        const bool rounds = ctx->kernel == 0 && ctx->units != 1;
+        const bool sample_units = rounds || ctx->units != 1;
+        const int blocks_per_cu = rounds ? ctx->rounds_blocks_per_cu : ctx->persistent_blocks_per_cu;
         const long units = sample_units ? pixels * rays_per_pixel : pixels;
         if ((unsigned long long)units >= 0x7fffffffull)
             return fail(TRT_ERR_ARGUMENT, "%ld work units exceed the 2^31 index range", units);
@@ -509,24 +519,35 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
             f.samples = ctx->d_samples.ptr;
             f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
         }
-        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units, ctx->persistent_blocks_per_cu, units);
+        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units, blocks_per_cu, units);
         const size_t plds = trt::persistent_lds_bytes(ctx->scene, rays_per_pixel);
         const dim3 grid(pl.grid), block(pl.block);
+        const bool count = ctx->counters_enabled;
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], ctx->stream));
-        if (sample_units)
+        if (rounds)
         {
-            if (ctx->counters_enabled)
+            if (count)
+                hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+            else
+                hipLaunchKernelGGL((trt::render_rounds_kernel<false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+        }
+        else if (sample_units)
+        {
+            if (count)
                 hipLaunchKernelGGL((trt::render_persistent_kernel<true, true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
             else
                 hipLaunchKernelGGL((trt::render_persistent_kernel<false, true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+        }
+        else if (count)
+            hipLaunchKernelGGL((trt::render_persistent_kernel<true, false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+        else
+            hipLaunchKernelGGL((trt::render_persistent_kernel<false, false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+        if (sample_units)
+        { // TRT.c:1063-1065: the mean over each pixel's samples, in sample order
             const long values = pixels * 3;
             hipLaunchKernelGGL(trt::reduce_samples_kernel, dim3((unsigned)((values + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const double *)ctx->d_samples.ptr, (double *)d_pixels, values, rays_per_pixel, f.inv_spp);
         }
-        else if (ctx->counters_enabled)
-            hipLaunchKernelGGL((trt::render_persistent_kernel<true, false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
-        else
-            hipLaunchKernelGGL((trt::render_persistent_kernel<false, false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
         HIP_TRY(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
     }
     HIP_TRY(hipGetLastError());
@@ -609,7 +630,9 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
     if (!ctx)
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel : (const void *)trt::render_persistent_kernel<false, false>;
+    const void *fn = ctx->kernel == 1   ? (const void *)trt::render_simple_kernel
+                     : ctx->kernel == 2 ? (const void *)trt::render_persistent_kernel<false, true>
+                                        : (const void *)trt::render_rounds_kernel<false>;
     hipFuncAttributes attr;
     HIP_TRY(hipFuncGetAttributes(&attr, fn));
     if (vgprs)
@@ -624,8 +647,10 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
         const size_t lds = ctx->have_scene ? (ctx->kernel == 1 ? scene_lds_bytes(ctx->scene) : trt::persistent_lds_bytes(ctx->scene, 64)) : 0;
         if (ctx->kernel == 1)
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_simple_kernel, 256, lds));
+        else if (ctx->kernel == 2)
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false, true>, trt::kPersistentBlock, lds));
         else
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false, false>, trt::kPersistentBlock, lds));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock, lds));
         *max_blocks_per_cu = blocks;
     }
     if (compute_units)

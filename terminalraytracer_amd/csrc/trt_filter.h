@@ -146,17 +146,48 @@ TRT_HD void trt_filter_setup(trt_ray_filter *f, double ox, double oy, double oz,
             __builtin_fabsf(f->cd_min) < __builtin_inff();
 }
 
+/* TRT_FILTER_BEHIND_TEST: 1 = the sweep also drops spheres whose centre lies behind the ray origin by more than
+ * the error bound (n < 0; 11 VALU per sphere); 0 = only the discriminant test (9 VALU per sphere) and the exact
+ * stage rejects those spheres (about twice the candidates, ~0.8 per ray instead of ~0.4). */
+#ifndef TRT_FILTER_BEHIND_TEST
+#define TRT_FILTER_BEHIND_TEST 0
+#endif
+
 /* sign word of one sphere for an ok ray: bit 31 set = reject */
 TRT_HD unsigned trt_filter_sign(const trt_ray_filter *f, float cx, float cy, float cz, float kk)
 {
     const float cd = __builtin_fmaf(cz, f->dz, __builtin_fmaf(cy, f->dy, cx * f->dx));
-    const float n = cd - f->cd_min;
     const float cw = __builtin_fmaf(cz, f->wz, __builtin_fmaf(cy, f->wy, __builtin_fmaf(cx, f->wx, f->neg_thr)));
     const float m = __builtin_fmaf(cd, cd, cw) - kk;
-    unsigned mb, nb;
+    unsigned mb;
     __builtin_memcpy(&mb, &m, 4);
+#if TRT_FILTER_BEHIND_TEST
+    const float n = cd - f->cd_min;
+    unsigned nb;
     __builtin_memcpy(&nb, &n, 4);
-    return mb | nb;
+    mb |= nb;
+#endif
+    return mb;
+}
+
+/* Rays of ONE fixed direction (the shadow rays of a directional light, TRT.c:903-907): cd = C.d is the same for
+ * every such ray, so it is folded into the table once, kk' = kk - cd*cd (FP32, two roundings), and the test
+ * shrinks to m = (C.W - thr) - kk'.  Compared with trt_filter_sign this only moves cd^2 from one FMA into a
+ * separately rounded product and difference: <= 3 eps Cn^2 more error, inside E's head-room. */
+TRT_HD float trt_filter_fixed_dir_kk(float cx, float cy, float cz, float kk, float dx, float dy, float dz)
+{
+    const float cd = __builtin_fmaf(cz, dz, __builtin_fmaf(cy, dy, cx * dx));
+    const float cd2 = cd * cd;
+    return kk - cd2;
+}
+
+TRT_HD unsigned trt_filter_sign_fixed_dir(const trt_ray_filter *f, float cx, float cy, float cz, float kk_fixed)
+{
+    const float cw = __builtin_fmaf(cz, f->wz, __builtin_fmaf(cy, f->wy, __builtin_fmaf(cx, f->wx, f->neg_thr)));
+    const float m = cw - kk_fixed;
+    unsigned mb;
+    __builtin_memcpy(&mb, &m, 4);
+    return mb;
 }
 
 TRT_HD int trt_filter_pass(const trt_ray_filter *f, float cx, float cy, float cz, float kk)

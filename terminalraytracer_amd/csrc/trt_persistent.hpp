@@ -101,8 +101,9 @@ inline size_t persistent_lds_bytes(const SceneView &s, int spp)
 {
     const size_t padded = ((size_t)s.num_spheres + kCullGroup - 1) / kCullGroup * kCullGroup;
     return sizeof(double) * ((size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * 6 +
-                             (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp +
-                             (TRT_SWEEP_LDS ? padded * 2 : 0) /* culling table first: 4 floats per sphere, 16-B aligned */);
+                             (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp + 1 /* 16-B alignment */ +
+                             (TRT_SWEEP_LDS ? padded * 2 : 0) /* culling table first: 4 floats per sphere, 16-B aligned */ +
+                             (size_t)s.num_dir * padded * 2 /* last: one fixed-direction table per directional light (rounds kernel) */);
 }
 
 struct CullView

@@ -1,0 +1,440 @@
+// trt_rounds.hpp -- production frame-producer kernel for gfx950: persistent waves, MODE-SYNCHRONOUS ROUNDS.
+//
+// Shape of the work: per pixel `spp` samples, per sample a bounce loop, per bounce one
+// closest-hit trace plus one shadow trace per light; a trace = N sphere tests + 1 plane test.
+//
+// Work units are single SAMPLES (unit = pixel*spp + k), pulled from a global queue a chunk at a time into a
+// wave-level pool.  A lane always owns exactly one pending PATH ray.  One round of the main loop advances
+// every lane's path by one ray:
+//
+//   P      closest hit of the path ray, all lanes (TRT.c:1024)
+//          sky  -> skybox texel, the sample ends (TRT.c:858-867, 1044-1048)
+//          hit  -> nudged point, unit normal, material (TRT.c:868-886)
+//   S(i)   for every light i (wave-uniform loop): shadow ray from the hit point for the lanes that hit something
+//          (TRT.c:900-957); directional lights only ask "anything in the way?", so their search stops at the
+//          first hit; lit colour accumulates in the reference's light order
+//   END    bounce bookkeeping (TRT.c:1034-1056); a finished sample is normalised by its weight (TRT.c:1061),
+//          written to f.samples[unit] and the lane pulls its next unit; one shared unit() gives every lane its
+//          next direction (mirror reflection or fresh primary ray)
+//
+// Because all lanes of a wave are in the same stage, there is no per-lane state machine and no merging of
+// modes; the code of each stage is straight-line with exec masking only for "hit" vs "sky".  The price is
+// that lanes whose path ray reached the sky idle through the shadow stages of that round (the sphere sweep is
+// wave-uniform work, so it costs the same whether 36 or 64 lanes take part).
+//
+// The trace itself is the two-phase search described in trt_filter.h / trt_persistent.hpp: a wave-uniform FP32
+// sweep over a culling table in LDS (broadcast ds_read_b128, 11 VALU per sphere, verdict in a sign bit)
+// followed by per-lane EXACT FP64 tests of the few candidates in ascending index order.  FP64, contraction
+// off: results are bit-identical to the reference.  The mean over a pixel's samples is formed by
+// reduce_samples_kernel in the reference's order (TRT.c:1063-1065).
+#pragma once
+
+#include "trt_device.hpp"
+#include "trt_filter.h"
+#include "trt_persistent.hpp"
+
+namespace trt
+{
+
+struct LdsImage
+{
+    const float4 *cull;  // culling table {Cx,Cy,Cz,kk}
+    const float4 *cull_dir; // per directional light: {Cx,Cy,Cz,kk - (C.d)^2}, `padded` entries each
+    const double *cx, *cy, *cz, *r2;
+    const double *mat;   // (n+2) x {colour, reflectivity, specularity}: spheres, ground even, ground odd
+    const double *dir;   // per directional light: unit to-light (3), colour (3)
+    const double *pt;    // per point light: position (3), colour (3), intensity
+    const double *b255;  // byte / 255.0
+    const double *cam;   // basis x,y,z (9), eye (3), -screen_distance
+    const double *jit;   // jitter x[spp], y[spp]
+};
+
+// same layout and size as trt_persistent.hpp (persistent_lds_bytes)
+TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView &cull, const FrameView &f)
+{
+    const int n = s.num_spheres, nd = s.num_dir, np = s.num_point;
+    float4 *l_cull = (float4 *)lds;
+    double *l_cx = lds + cull.padded * 2, *l_cy = l_cx + n, *l_cz = l_cy + n, *l_r2 = l_cz + n;
+    double *l_mat = l_r2 + n, *l_dir = l_mat + (n + 2) * 5, *l_pt = l_dir + nd * 6, *l_255 = l_pt + np * 7;
+    double *l_cam = l_255 + 256, *l_jit = l_cam + kLdsCameraDoubles;
+    for (int i = threadIdx.x; i < cull.padded; i += blockDim.x)
+        l_cull[i] = ((const float4 *)cull.table)[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+    {
+        const double *sp = s.spheres + (long)i * kSphereDoubles;
+        l_cx[i] = sp[0];
+        l_cy[i] = sp[1];
+        l_cz[i] = sp[2];
+        l_r2[i] = sp[3] * sp[3]; // radius*radius exactly as TRT.c:648 forms it
+        for (int j = 0; j < 5; j++)
+            l_mat[i * 5 + j] = sp[4 + j];
+    }
+    for (int i = threadIdx.x; i < 10; i += blockDim.x)
+        l_mat[n * 5 + i] = s.ground[6 + i];
+    for (int i = threadIdx.x; i < nd; i += blockDim.x)
+    {
+        const double *li = s.dir_lights + i * kDirLightDoubles;
+        const d3 tl = unit(scale(load3(li), -1.0)); // TRT.c:903-904, the same value for every hit point
+        l_dir[i * 6 + 0] = tl.x, l_dir[i * 6 + 1] = tl.y, l_dir[i * 6 + 2] = tl.z;
+        l_dir[i * 6 + 3] = li[3], l_dir[i * 6 + 4] = li[4], l_dir[i * 6 + 5] = li[5];
+    }
+    for (int i = threadIdx.x; i < np * 7; i += blockDim.x)
+        l_pt[i] = s.point_lights[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x)
+        l_255[i] = (double)i / 255.0; // TRT.c:866
+    for (int i = threadIdx.x; i < 12; i += blockDim.x)
+        l_cam[i] = f.cam[i];
+    if (threadIdx.x == 0)
+        l_cam[12] = -f.cam[12]; // TRT.c:989
+    for (int i = threadIdx.x; i < 2 * f.spp; i += blockDim.x)
+        l_jit[i] = f.jitter[i];
+    // fixed-direction tables behind everything else, on a 16-byte boundary (all offsets above are whole doubles)
+    const long dir_tables_at = ((l_jit + 2 * f.spp) - lds + 1) & ~1L;
+    float4 *l_cull_dir = (float4 *)(lds + dir_tables_at);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nd * cull.padded; i += blockDim.x)
+    {
+        const int li = i / cull.padded, j = i - li * cull.padded;
+        const float4 e = l_cull[j];
+        const float dx = (float)l_dir[li * 6 + 0], dy = (float)l_dir[li * 6 + 1], dz = (float)l_dir[li * 6 + 2]; // = trt_filter_setup's d
+        l_cull_dir[i] = float4{e.x, e.y, e.z, trt_filter_fixed_dir_kk(e.x, e.y, e.z, e.w, dx, dy, dz)};
+    }
+    __syncthreads();
+    return LdsImage{l_cull, l_cull_dir, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit};
+}
+
+struct Hit
+{
+    double d2; // squared distance origin -> (un-nudged) hit point, TRT.c:815
+    d3 p;      // hit point as the intersection routine produced it
+    int i;     // -1: nothing; [0,n): sphere; n: ground
+};
+
+// Closest hit of TRT.c:793-856 for the lanes with `active`.  ANY_HIT: the caller only asks whether anything
+// is hit (directional-light shadow ray, TRT.c:908), so a lane stops at its first hit and the ground is skipped
+// once a sphere was found.
+// `fixed` != nullptr: all rays of this call share the direction the table was built for (directional light).
+template <bool ANY_HIT>
+TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
+                  const float4 *fixed = nullptr)
+{
+    Hit best;
+    best.d2 = __builtin_inf();
+    best.p = o;
+    best.i = -1;
+    const double a = dot(d, d);
+    trt_ray_filter flt;
+    trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
+
+    for (int base = 0; base < cull.padded; base += 64)
+    {
+        // phase 1: wave-uniform sweep; each verdict is a sign bit shifted into a per-lane word by v_alignbit,
+        // sphere base+j ends up at bit 63-j of `cand`
+        const int chunk = (cull.padded - base) < 64 ? (cull.padded - base) : 64;
+        unsigned word[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const int first = base + 32 * h, count = (chunk - 32 * h) < 32 ? (chunk - 32 * h) : 32;
+            unsigned bits = ~0u;
+            for (int g = 0; g < count; g += kCullGroup)
+            {
+#pragma unroll
+                for (int j = 0; j < kCullGroup; j++)
+                {
+                    if (ANY_HIT && fixed)
+                    {
+                        const float4 e = fixed[first + g + j];
+                        bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign_fixed_dir(&flt, e.x, e.y, e.z, e.w), 31);
+                    }
+                    else
+                    {
+                        const float4 e = L.cull[first + g + j]; // same address in every lane: LDS broadcast
+                        bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign(&flt, e.x, e.y, e.z, e.w), 31);
+                    }
+                }
+            }
+            word[h] = count > 0 ? ~(bits << (32 - count)) & (count == 32 ? ~0u : ~((1u << (32 - count)) - 1u)) : 0u;
+        }
+        unsigned long long cand = ((unsigned long long)word[0] << 32) | word[1];
+        if (!flt.ok)
+            cand = chunk == 64 ? ~0ull : ~((1ull << (64 - chunk)) - 1ull); // degenerate ray: every sphere of the chunk
+        if (!active)
+            cand = 0;
+        // phase 2: exact FP64 tests of this lane's candidates, ascending index (first index wins ties, TRT.c:816)
+        while (__any(cand != 0))
+        {
+            phase2_rounds++;
+            if (cand != 0)
+            {
+                const int lead = __builtin_clzll(cand);
+                const int i = base + lead;
+                cand &= ~(0x8000000000000000ull >> lead);
+                if (i < n)
+                {
+                    const d3 c = d3{L.cx[i], L.cy[i], L.cz[i]};
+                    const d3 oc = sub(o, c);
+                    const double b = 2.0 * dot(oc, d);
+                    const double cc = dot(oc, oc) - L.r2[i];
+                    const double disc = b * b - 4.0 * a * cc;
+                    if (!(disc < 0.0))
+                    {
+                        const double t0 = (-b - __builtin_sqrt(disc)) / (2.0 * a);
+                        if (t0 > 0.0)
+                        {
+                            const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
+                            const double d2 = dist2(o, p);
+                            if (d2 < best.d2)
+                            {
+                                best.d2 = d2;
+                                best.p = p;
+                                best.i = i;
+                            }
+                            if (ANY_HIT)
+                                cand = 0;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ground plane (TRT.c:831-853)
+    if (active && !(ANY_HIT && best.i >= 0))
+    {
+        d3 p;
+        if (hit_plane(o, d, gp, gn, p))
+        {
+            const double d2 = dist2(o, p);
+            if (d2 < best.d2)
+            {
+                best.d2 = d2;
+                best.p = p;
+                best.i = n;
+            }
+        }
+    }
+    return best;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const LdsImage L = stage_lds_image(lds, s, cull, f);
+    const int n = s.num_spheres, nd = s.num_dir, nl = s.num_dir + s.num_point;
+    const int lane = threadIdx.x & 63;
+    const unsigned total = (unsigned)f.local_rows * (unsigned)f.width * (unsigned)f.spp; // work units, < 2^31
+    const d3 gp = load3(s.ground), gn = load3(s.ground + 3);
+
+    // ---- per-lane state ------------------------------------------------------------------------------
+    bool alive = true;             // owns a unit (a sample being traced)
+    bool want_unit = true;         // needs a (new) unit before the next round
+    unsigned unit_id = 0;          // pixel*spp + k
+    d3 sample = d3{0.0, 0.0, 0.0}; // pixel_color of the sample (TRT.c:1012)
+    double weight = 1.0, weight_sum = 0.0;
+    int bounces = 0;
+    d3 o = d3{0.0, 0.0, 0.0}, d = d3{0.0, 0.0, -1.0}; // the pending path ray
+    d3 next_dir = d;                                  // un-normalised direction of the next path ray
+    unsigned n_path = 0, n_shadow = 0, n_rounds = 0, n_phase2 = 0;
+    unsigned pool_next = 0, pool_end = 0; // wave-uniform: units fetched from the queue, not yet handed out
+
+#if TRT_STAMP
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    for (;;)
+    {
+        TRT_STAMP_AT(7); // END of bounce + loop edge
+        // =============== hand out work units; primary rays of new samples (TRT.c:981-1016) ===============
+        {
+            const unsigned long long need = __ballot(want_unit);
+            if (need)
+            {
+                const unsigned wanted = (unsigned)__builtin_popcountll(need);
+                const unsigned rank = (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+                unsigned mine = pool_next + rank;
+                if (pool_end - pool_next < wanted)
+                { // refill the wave's pool with ONE atomic; what is left of the old chunk is served first
+                    const unsigned left = pool_end - pool_next;
+                    unsigned fresh = 0;
+                    const int leader = __builtin_ctzll(need);
+                    if (lane == leader)
+                        fresh = atomicAdd(f.queue, kQueueChunkSamples);
+                    fresh = __shfl(fresh, leader);
+                    if (rank >= left)
+                        mine = fresh + (rank - left);
+                    pool_next = fresh + (wanted - left);
+                    pool_end = fresh + kQueueChunkSamples;
+                }
+                else
+                    pool_next += wanted;
+                if (want_unit)
+                {
+                    alive = mine < total;
+                    if (alive)
+                    {
+                        unit_id = mine;
+                        // unit -> (pixel, k) -> (row, column) by multiply-high with min(ceil(2^32/x), 2^32-1): off by at most one
+                        unsigned pixel = __umulhi(mine, f.spp_magic);
+                        int k = (int)(mine - pixel * (unsigned)f.spp);
+                        if (k < 0)
+                            pixel--, k += f.spp;
+                        else if (k >= f.spp)
+                            pixel++, k -= f.spp;
+                        unsigned row = __umulhi(pixel, f.width_magic);
+                        int col = (int)(pixel - row * (unsigned)f.width);
+                        if (col < 0)
+                            row--, col += f.width;
+                        else if (col >= f.width)
+                            row++, col -= f.width;
+                        const double sx = f.col_x[col] + L.jit[k];
+                        const double sy = f.row_y[frame_row_of(f, (int)row)] + L.jit[f.spp + k];
+                        d3 dir = d3{0.0, 0.0, 0.0};
+                        dir = add(dir, scale(load3(L.cam + 0), sx));
+                        dir = add(dir, scale(load3(L.cam + 3), sy));
+                        dir = add(dir, scale(load3(L.cam + 6), L.cam[12]));
+                        next_dir = sub(dir, load3(L.cam + 9)); // sic, TRT.c:1005
+                        o = load3(L.cam + 9);
+                        sample = d3{0.0, 0.0, 0.0};
+                        weight = 1.0;
+                        weight_sum = 0.0;
+                        bounces = 0;
+                    }
+                    want_unit = false;
+                }
+            }
+        }
+        if (!__any(alive))
+            break;
+        if (COUNT)
+            n_rounds++;
+        TRT_STAMP_AT(0); // units + primary rays
+        d = unit(next_dir); // TRT.c:1008 for a primary ray, TRT.c:1055 for a reflected one
+
+        // ======================================= P: the path ray =======================================
+        if (COUNT && alive)
+            n_path++;
+        TRT_STAMP_AT(1); // unit(next_dir)
+        const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2);
+        TRT_STAMP_AT(2); // P trace
+        const bool path_hit = alive && ph.i >= 0, path_sky = alive && ph.i < 0;
+
+        // one unit() for "back along the ray" (nudge, TRT.c:871-872) or the sky direction (TRT.c:702), one for the normal
+        const d3 nA = unit(path_hit ? sub(o, ph.p) : d);
+        d3 h_normal = d, lit = d3{0.0, 0.0, 0.0};
+        int h_mat = 0;
+        if (__any(path_hit))
+        {
+            d3 raw = gn;
+            h_mat = n + checker_odd(ph.p); // TRT.c:850-851 (only meaningful for a ground hit)
+            if (ph.i >= 0 && ph.i < n)
+            {
+                raw = sub(ph.p, d3{L.cx[ph.i], L.cy[ph.i], L.cz[ph.i]}); // TRT.c:824
+                h_mat = ph.i;
+            }
+            h_normal = unit(raw); // TRT.c:878
+        }
+        bool end_sample = false;
+        double weight_sum_new = weight_sum + weight; // TRT.c:1034
+        if (path_sky)
+        { // TRT.c:858-867, :1044-1048: colour = texel, the sample ends here
+            const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, nA);
+            const d3 color = d3{L.b255[t & 0xFF], L.b255[(t >> 8) & 0xFF], L.b255[(t >> 16) & 0xFF]};
+            sample = add(sample, scale(color, weight));
+            end_sample = true;
+        }
+        if (path_hit)
+        {
+            next_dir = reflect(d, h_normal);        // TRT.c:1054, normalised at the top of the next round
+            o = add(ph.p, scale(nA, 0.000001));     // TRT.c:873-874; origin of the shadow rays and of the next path ray
+        }
+
+        TRT_STAMP_AT(3); // P post: nudge/normal/sky
+        // ======================================= S(i): shadow rays =======================================
+        if (__any(path_hit))
+        {
+            for (int li = 0; li < nl; li++)
+            {
+                if (COUNT && path_hit)
+                    n_shadow++;
+                d3 sd, lcolor;
+                bool is_lit;
+                double factor;
+                if (li < nd)
+                { // directional light, TRT.c:900-923
+                    sd = load3(L.dir + li * 6);
+                    lcolor = load3(L.dir + li * 6 + 3);
+                    const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, L.cull_dir + li * cull.padded);
+                    is_lit = sh.i < 0;
+                    factor = min1(dot(h_normal, sd));
+                    TRT_STAMP_AT(4); // directional shadow
+                }
+                else
+                { // point light, TRT.c:926-957
+                    const double *pl = L.pt + (li - nd) * 7;
+                    const d3 to_light = sub(load3(pl), o);
+                    const double light_d2 = dot(to_light, to_light);
+                    const double strength = clampd(pl[6] / light_d2, 0.0, 1.0);
+                    sd = unit(to_light);
+                    lcolor = load3(pl + 3);
+                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2);
+                    is_lit = sh.i < 0;
+                    if (__any(path_hit && sh.i >= 0))
+                    { // a blocker: is it farther than the light?  distance to the NUDGED blocker point, TRT.c:939-942
+                        const d3 to_blocker = sub(add(sh.p, scale(unit(sub(o, sh.p)), 0.000001)), o);
+                        if (sh.i >= 0)
+                            is_lit = light_d2 < dot(to_blocker, to_blocker);
+                    }
+                    factor = strength * min1(dot(h_normal, sd));
+                    TRT_STAMP_AT(5); // point shadow
+                }
+                if (path_hit && is_lit)
+                    lit = add(lit, mulc(scale(lcolor, factor), load3(L.mat + h_mat * 5)));
+            }
+        }
+
+        TRT_STAMP_AT(6); // lit accumulate
+        // ======================================= END of the bounce =======================================
+        if (path_hit)
+        { // TRT.c:960-962 then :1034-1048
+            d3 color = d3{clampd(lit.x, 0.0, 1.0), clampd(lit.y, 0.0, 1.0), clampd(lit.z, 0.0, 1.0)};
+            color = scale(color, weight);
+            weight *= L.mat[h_mat * 5 + 3];
+            bounces++;
+            sample = add(sample, color);
+            if (bounces < f.bounce_limit && weight > 0.00001) // TRT.c:1018
+                weight_sum = weight_sum_new;
+            else
+                end_sample = true;
+        }
+        if (__any(end_sample))
+        { // TRT.c:1061: the sample's colour, normalised by the weights it gathered
+            const double q = 1.0 / weight_sum_new;
+            if (end_sample)
+            {
+                double *out = f.samples + (size_t)unit_id * 3;
+                out[0] = sample.x * q;
+                out[1] = sample.y * q;
+                out[2] = sample.z * q;
+                want_unit = true;
+            }
+        }
+    }
+
+    if (COUNT && f.counters)
+    {
+        atomicAdd(&f.counters[0], (unsigned long long)n_path);
+        atomicAdd(&f.counters[1], (unsigned long long)n_shadow);
+        if (lane == 0)
+        {
+            atomicAdd(&f.counters[2], (unsigned long long)n_rounds);
+            atomicAdd(&f.counters[3], (unsigned long long)n_phase2);
+#if TRT_STAMP
+            for (int i = 0; i < 8; i++)
+                atomicAdd(&f.counters[4 + i], stamp_sum[i]);
+#endif
+        }
+    }
+}
+
+} // namespace trt

@@ -110,7 +110,7 @@ def camera_struct(camera_array):
 class Context:
     """One renderer on one GPU (trt_context)."""
 
-    PRODUCTION, REFERENCE_ORDER = 0, 1
+    PRODUCTION, REFERENCE_ORDER, STATE_MACHINE = 0, 1, 2
 
     def __init__(self, device=0):
         self._h = _VP()

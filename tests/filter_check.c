@@ -88,3 +88,53 @@ void filter_check(const double *spheres, int n, const double *rays, size_t n_ray
     }
     free(table);
 }
+
+/* Fixed-direction variant (directional-light shadow rays): every ray shares the direction of rays[3..5].
+ * The table carries kk' = kk - (C.d)^2 exactly as the rounds kernel builds it. */
+void filter_check_fixed_dir(const double *spheres, int n, const double *rays, size_t n_rays, filter_stats *st)
+{
+    memset(st, 0, sizeof *st);
+    if (!n_rays)
+        return;
+    const int group = 16, padded = trt_cull_padded(n, group);
+    float *table = (float *)malloc(sizeof(float) * 4 * (size_t)(padded ? padded : 1));
+    trt_cull_scene cs;
+    trt_cull_build(spheres, n, group, table, &cs);
+    const float dx = (float)rays[3], dy = (float)rays[4], dz = (float)rays[5];
+    for (int i = 0; i < padded; i++)
+        table[4 * i + 3] = trt_filter_fixed_dir_kk(table[4 * i], table[4 * i + 1], table[4 * i + 2], table[4 * i + 3], dx, dy, dz);
+    for (size_t r = 0; r < n_rays; r++)
+    {
+        const double *o = rays + 6 * r, *d = o + 3;
+        const double a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        trt_ray_filter f;
+        trt_filter_setup(&f, o[0], o[1], o[2], d[0], d[1], d[2], a, cs.c0[0], cs.c0[1], cs.c0[2], cs.cn, cs.rm);
+        unsigned cand = 0, hits = 0;
+        for (int i = 0; i < n; i++)
+        {
+            const int pass = !f.ok || !(trt_filter_sign_fixed_dir(&f, table[4 * i], table[4 * i + 1], table[4 * i + 2], table[4 * i + 3]) >> 31);
+            double disc;
+            const int e = exact_hit(o, d, a, spheres + 9 * i, &disc);
+            st->pairs++;
+            st->line_hits += e >= 1;
+            st->exact_hits += e == 2;
+            hits += e == 2;
+            cand += pass != 0;
+            st->passed += pass != 0;
+            if (e == 2 && !pass)
+            {
+                if (!st->violations)
+                {
+                    memcpy(st->first_violation, o, 6 * sizeof(double));
+                    st->first_violation[6] = i;
+                    st->first_violation[7] = disc;
+                }
+                st->violations++;
+            }
+        }
+        st->rays++;
+        st->cand_hist[cand > 16 ? 16 : cand]++;
+        st->hit_hist[hits > 16 ? 16 : hits]++;
+    }
+    free(table);
+}

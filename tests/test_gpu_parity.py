@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 SMALL = T.golden_cases(("small", "medium"))
 LARGE = T.golden_cases(("large",))
 # (kernel, work units): production kernel with pixels / samples as work units, and the reference-order kernel
-KERNELS = [(hip.Context.PRODUCTION, 1), (hip.Context.PRODUCTION, 2), (hip.Context.REFERENCE_ORDER, 0)]
-KERNEL_IDS = ["production_pixel_units", "production_sample_units", "reference_order"]
+KERNELS = [(hip.Context.PRODUCTION, 0), (hip.Context.STATE_MACHINE, 1), (hip.Context.STATE_MACHINE, 2),
+           (hip.Context.REFERENCE_ORDER, 0)]
+KERNEL_IDS = ["production_rounds", "state_machine_pixel_units", "state_machine_sample_units", "reference_order"]
 
 
 @pytest.fixture(scope="module")
@@ -119,10 +120,10 @@ def test_north_star_config_production_equals_reference_order_and_oracle(ctx):
     w, h = 1920, 1080
     scene = S.synth_scene(64, S.synth_sky(256), T.bench_camera(w, h), seed=1234)
     fast = render(ctx, scene, w, h, 8, 10, KERNELS[0])
-    fast2 = render(ctx, scene, w, h, 8, 10, KERNELS[1])
-    slow = render(ctx, scene, w, h, 8, 10, KERNELS[2])
+    slow = render(ctx, scene, w, h, 8, 10, KERNELS[3])
     assert np.array_equal(bits(fast), bits(slow))
-    assert np.array_equal(bits(fast2), bits(slow))
+    for other in KERNELS[1:3]:
+        assert np.array_equal(bits(render(ctx, scene, w, h, 8, 10, other)), bits(slow))
     band, _ = T.oracle_render(scene, w, h, 8, 10, rows=(530, 562))  # rows through the sphere field
     assert np.array_equal(bits(fast[530:562]), bits(band))
     assert np.isfinite(fast).all() and fast.min() >= 0.0 and fast.max() <= 1.0
@@ -138,7 +139,7 @@ def test_row_tile_shards_reassemble_to_the_whole_frame(ctx, world, tile, units):
     out = np.zeros_like(whole)
     for rank in range(world):
         rs = hip.RowSet.shard(w, h, rank, world, tile)
-        part = render(ctx, scene, w, h, 8, 10, (hip.Context.PRODUCTION, units), rows=rs)
+        part = render(ctx, scene, w, h, 8, 10, (hip.Context.PRODUCTION if units == 2 else hip.Context.STATE_MACHINE, units), rows=rs)
         for i in range(part.shape[0]):
             out[hip.lib().trt_rowset_frame_row(C.byref(rs), i)] = part[i]
     assert np.array_equal(bits(out), bits(whole))
