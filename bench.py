@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=0, help="0 production, 1 reference-order (debug)")
     ap.add_argument("--units", type=int, default=0, help="work units of the production kernel: 0 auto, 1 pixels, 2 samples")
+    ap.add_argument("--depth", type=int, default=2, help="frames in flight per GPU (1 = strictly one frame at a time)")
     args = ap.parse_args()
 
     import torch
@@ -112,9 +113,8 @@ def main():
     torch.cuda.set_device(local)
 
     scene = build_scene()
-    r = HipShardRenderer(scene, W, H, rank, world, local, BOUNCES, SPP)
-    r.ctx.set_kernel(args.kernel)
-    r.ctx.set_work_units(args.units)
+    r = HipShardRenderer(scene, W, H, rank, world, local, BOUNCES, SPP, depth=args.depth)
+    r.for_each_context(lambda c: (c.set_kernel(args.kernel), c.set_work_units(args.units)))
 
     # untimed: per-frame ray counts of this rank's rows (counting variant of the kernel)
     r.ctx.enable_counters(True)
@@ -123,6 +123,9 @@ def main():
     path_rays, shadow_rays = r.ctx.read_counters()
     diag = r.ctx.read_diagnostics()
     r.ctx.enable_counters(False)
+    for _ in range(args.depth - 1):  # bring every slot to the same state before warm-up
+        r.render(scene.camera)
+    torch.cuda.synchronize()
     counts = torch.tensor([path_rays, shadow_rays], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
         dist.all_reduce(counts)
@@ -145,7 +148,7 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     seconds = float(elapsed.item())
 
-    kernel_ms = r.ctx.kernel_times(args.steps)  # HIP events on the launch stream, the timed launches only
+    kernel_ms = r.kernel_times(args.steps)  # HIP events on each launch stream, the timed launches only
     if rank == 0:
         ms_step = seconds / args.steps * 1e3
         kavg = float(np.mean(kernel_ms))
@@ -163,14 +166,18 @@ def main():
             "config": {"workload": "BASELINE configs[2]: 1920x1080, SYNTH-v0 64 spheres seed 1234 + checker floor, "
                                    "1 directional + 1 point light, 8 bounces, 10 rays/pixel, 256^2 procedural cubemap, "
                                    "off-screen f64 framebuffer", "sharding": f"{world} x interleaved 8-row tiles, 1 gather/frame",
-                       "kernel": "persistent state machine" if args.kernel == 0 else "reference-order"},
+                       "kernel": {0: "persistent waves, synchronous rounds", 1: "reference-order", 2: "persistent state machine"}[args.kernel],
+                       "frames_in_flight": args.depth},
             "rays_per_frame": {"path": path_total, "shadow": shadow_total},
             "all_rays_per_s": (path_total + shadow_total) * args.steps / seconds,
             "kernel_ms_avg": kavg,
+            "frames_in_flight": args.depth,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic()[0] if world == 1 else None,
                          "algorithmic_bytes": alg,
-                         "note": "VALU-issue-bound path: algorithmic HBM bytes are ~1 B/ray (SURVEY 8d); see fp64_valu and DESIGN.md 5"},
+                         "note": "VALU-issue-bound path: algorithmic HBM bytes are ~1 B/ray (SURVEY 8d); see fp64_valu and DESIGN.md 5. "
+                                 "achieved = algorithmic bytes per launch / average launch duration (HIP events); with "
+                                 "frames_in_flight > 1 launches overlap, so a launch lasts longer than ms_per_step"},
             "fp64_valu": {"achieved_tflops_reference_opcount": flops / (kavg * 1e-3) / 1e12, "peak_tflops_fma": FP64_PEAK_TFLOPS,
                           "peak_tflops_no_fma": FP64_PEAK_TFLOPS / 2,
                           "note": "reference op count 25*N+17 per trace; the kernel does fewer ops than that (FP32 culling)"},
