@@ -643,7 +643,11 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
             sample = scale(sample, q);
             if (SAMPLE_UNITS)
             {
-                double *out = f.samples + (size_t)pix * 3;
+                const unsigned px_ = __umulhi(pix, f.spp_magic); // unit -> (pixel, k) once more for the sample-major slot
+                int k_ = (int)(pix - px_ * (unsigned)f.spp);
+                const unsigned pixel_ = k_ < 0 ? px_ - 1 : (k_ >= f.spp ? px_ + 1 : px_);
+                k_ = (int)(pix - pixel_ * (unsigned)f.spp);
+                double *out = f.samples + ((size_t)k_ * ((size_t)f.local_rows * f.width) + pixel_) * 3;
                 out[0] = sample.x;
                 out[1] = sample.y;
                 out[2] = sample.z;
@@ -704,18 +708,17 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
     }
 }
 
-// TRT.c:1063-1066 for SAMPLE_UNITS frames: pixel = ((0 + s0) + s1 + ... ) * (1/spp), samples in index order
+// TRT.c:1063-1066 for frames rendered with samples as work units: pixel = (((0 + s0) + s1) + ...) * (1/spp),
+// samples in index order.  The scratch is sample-major, samples[(k*pixels + pixel)*3 + channel], so that for every k
+// consecutive threads read consecutive doubles (a pure streaming kernel: spp*24 B read + 24 B written per pixel).
 __global__ __launch_bounds__(256) void reduce_samples_kernel(const double *samples, double *out, long values, int spp, double inv_spp)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; // one thread per colour channel of a pixel
     if (i >= values)
         return;
-    const long pixel = i / 3;
-    const int channel = (int)(i - pixel * 3);
-    const double *src = samples + pixel * spp * 3 + channel;
     double mean = 0.0;
     for (int k = 0; k < spp; k++)
-        mean += src[k * 3];
+        mean += samples[(long)k * values + i];
     out[i] = mean * inv_spp;
 }
 

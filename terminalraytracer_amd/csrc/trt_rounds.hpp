@@ -223,13 +223,15 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
     const LdsImage L = stage_lds_image(lds, s, cull, f);
     const int n = s.num_spheres, nd = s.num_dir, nl = s.num_dir + s.num_point;
     const int lane = threadIdx.x & 63;
-    const unsigned total = (unsigned)f.local_rows * (unsigned)f.width * (unsigned)f.spp; // work units, < 2^31
+    const unsigned pixels_here = (unsigned)f.local_rows * (unsigned)f.width;
+    const unsigned total = pixels_here * (unsigned)f.spp; // work units, < 2^31
     const d3 gp = load3(s.ground), gn = load3(s.ground + 3);
 
     // ---- per-lane state ------------------------------------------------------------------------------
     bool alive = true;             // owns a unit (a sample being traced)
     bool want_unit = true;         // needs a (new) unit before the next round
     unsigned unit_id = 0;          // pixel*spp + k
+    unsigned slot_id = 0;          // k*pixels + pixel: where the sample's colour goes in f.samples
     d3 sample = d3{0.0, 0.0, 0.0}; // pixel_color of the sample (TRT.c:1012)
     double weight = 1.0, weight_sum = 0.0;
     int bounces = 0;
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
                             pixel--, k += f.spp;
                         else if (k >= f.spp)
                             pixel++, k -= f.spp;
+                        slot_id = (unsigned)k * pixels_here + pixel; // sample-major scratch: the reduction streams it
                         unsigned row = __umulhi(pixel, f.width_magic);
                         int col = (int)(pixel - row * (unsigned)f.width);
                         if (col < 0)
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
             const double q = 1.0 / weight_sum_new;
             if (end_sample)
             {
-                double *out = f.samples + (size_t)unit_id * 3;
+                double *out = f.samples + (size_t)slot_id * 3;
                 out[0] = sample.x * q;
                 out[1] = sample.y * q;
                 out[2] = sample.z * q;
