@@ -73,9 +73,12 @@ typedef struct
 
 /* Build the culling table for n spheres given as the reference's 9-double Sphere records
  * (TRT.c:161-166: centre xyz, radius, material...).  table must hold 4*padded floats where
- * padded = n rounded up to a multiple of `group`; pad entries carry kk = +inf and never pass.
+ * padded = n rounded up to a multiple of `group`; pad entries carry kk = 3e38 and never pass.
  * C = c - c0 with c0 the centre of the centres' bounding box; kk = |C|^2 - r^2; both are formed
  * in FP64 and rounded once. */
+/* kk of a padding entry: large and FINITE (never passes; 0 * kk stays 0 in the MFMA form of the sweep) */
+#define TRT_CULL_PAD_KK 3.0e38f
+
 static inline int trt_cull_padded(int n, int group) { return (n + group - 1) / group * group; }
 
 static inline void trt_cull_build(const double *spheres, int n, int group, float *table, trt_cull_scene *cs)
@@ -108,7 +111,7 @@ static inline void trt_cull_build(const double *spheres, int n, int group, float
     for (int i = n; i < padded; i++)
     {
         table[4 * i + 0] = table[4 * i + 1] = table[4 * i + 2] = 0.0f;
-        table[4 * i + 3] = __builtin_inff();
+        table[4 * i + 3] = TRT_CULL_PAD_KK;
     }
     /* rounded UP: the bounds must not be under-estimated */
     cs->cn = __builtin_nextafterf((float)(cn * (1.0 + 1e-6)), __builtin_inff());
@@ -185,6 +188,29 @@ TRT_HD unsigned trt_filter_sign_fixed_dir(const trt_ray_filter *f, float cx, flo
 {
     const float cw = __builtin_fmaf(cz, f->wz, __builtin_fmaf(cy, f->wy, __builtin_fmaf(cx, f->wx, f->neg_thr)));
     const float m = cw - kk_fixed;
+    unsigned mb;
+    __builtin_memcpy(&mb, &m, 4);
+    return mb;
+}
+
+/* The same tests in the operation order of the MFMA-fed sweep (csrc/trt_rounds.hpp): v_mfma_f32_32x32x2_f32 is an
+ * FMA chain over k = 0..3 (verified bit for bit by tools/mfma_probe), the 4th element of a sphere row is kk, the
+ * 4th element of a ray column is 0 for the d-product and -1 for the W-product, and the W accumulator starts at
+ * -thr:   cd = fma(kk,0, fma(Cz,dz, fma(Cy,dy, fma(Cx,dx, 0))));  cw = fma(kk,-1, fma(Cz,wz, fma(Cy,wy, fma(Cx,wx, -thr))));
+ *         m = fma(cd,cd,cw).     Same error bound as trt_filter_sign: the same roundings in another order. */
+TRT_HD unsigned trt_filter_sign_mfma(const trt_ray_filter *f, float cx, float cy, float cz, float kk)
+{
+    const float cd = __builtin_fmaf(kk, 0.0f, __builtin_fmaf(cz, f->dz, __builtin_fmaf(cy, f->dy, __builtin_fmaf(cx, f->dx, 0.0f))));
+    const float cw = __builtin_fmaf(kk, -1.0f, __builtin_fmaf(cz, f->wz, __builtin_fmaf(cy, f->wy, __builtin_fmaf(cx, f->wx, f->neg_thr))));
+    const float m = __builtin_fmaf(cd, cd, cw);
+    unsigned mb;
+    __builtin_memcpy(&mb, &m, 4);
+    return mb;
+}
+
+TRT_HD unsigned trt_filter_sign_fixed_dir_mfma(const trt_ray_filter *f, float cx, float cy, float cz, float kk_fixed)
+{
+    const float m = __builtin_fmaf(kk_fixed, -1.0f, __builtin_fmaf(cz, f->wz, __builtin_fmaf(cy, f->wy, __builtin_fmaf(cx, f->wx, f->neg_thr))));
     unsigned mb;
     __builtin_memcpy(&mb, &m, 4);
     return mb;

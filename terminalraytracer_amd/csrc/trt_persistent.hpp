@@ -103,7 +103,8 @@ inline size_t persistent_lds_bytes(const SceneView &s, int spp)
     return sizeof(double) * ((size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * 6 +
                              (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp + 1 /* 16-B alignment */ +
                              (TRT_SWEEP_LDS ? padded * 2 : 0) /* culling table first: 4 floats per sphere, 16-B aligned */ +
-                             (size_t)s.num_dir * padded * 2 /* last: one fixed-direction table per directional light (rounds kernel) */);
+                             (size_t)s.num_dir * padded * 2 /* one fixed-direction table per directional light (rounds kernel) */ +
+                             (2 + (size_t)s.num_dir) * (((size_t)s.num_spheres + 63) / 64 * 64) /* MFMA A-operand images, 2*padded64 floats each (rounds kernel) */);
 }
 
 struct CullView

@@ -36,10 +36,25 @@
 namespace trt
 {
 
+// TRT_SWEEP_MFMA: 0 (default) = phase 1 on the VALU (LDS-broadcast table, 9 / 5 VALU per sphere); 1 = phase 1 on the
+// matrix cores (sweep64_mfma below).  Both are exact; measured on MI355X at the north-star config, one frame in flight:
+//   VALU sweep, 125 VGPRs, 4 waves/SIMD                         3.30 ms
+//   MFMA sweep, 166 VGPRs, 3 waves/SIMD                         3.34 ms   (6 % faster than the VALU sweep at 3 waves)
+//   MFMA sweep forced to 128 VGPRs (140 B/lane of scratch)      3.75 ms
+// The 32 accumulator registers of a 32x32 tile pair cost the fourth wave, which is worth more than the offload.
+#ifndef TRT_SWEEP_MFMA
+#define TRT_SWEEP_MFMA 0
+#endif
+
 struct LdsImage
 {
     const float4 *cull;  // culling table {Cx,Cy,Cz,kk}
     const float4 *cull_dir; // per directional light: {Cx,Cy,Cz,kk - (C.d)^2}, `padded` entries each
+    // MFMA A-operand images of the same tables, per 64-sphere chunk two 32-sphere blocks of 64 floats each:
+    // a_xy[(2*chunk + blk)*64 + lane] = lane < 32 ? Cx : Cy of sphere 64*chunk + 32*blk + lane%32;  a_zk likewise Cz : kk
+    const float *a_xy, *a_zk;
+    const float *a_zk_dir; // per directional light, 2*padded64 floats each: Cz : kk - (C.d)^2
+    int padded64;
     const double *cx, *cy, *cz, *r2;
     const double *mat;   // (n+2) x {colour, reflectivity, specularity}: spheres, ground even, ground odd
     const double *dir;   // per directional light: unit to-light (3), colour (3)
@@ -99,8 +114,27 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
         const float dx = (float)l_dir[li * 6 + 0], dy = (float)l_dir[li * 6 + 1], dz = (float)l_dir[li * 6 + 2]; // = trt_filter_setup's d
         l_cull_dir[i] = float4{e.x, e.y, e.z, trt_filter_fixed_dir_kk(e.x, e.y, e.z, e.w, dx, dy, dz)};
     }
+    __syncthreads(); // the images below are built from l_cull_dir
+    // MFMA operand images behind the fixed-direction tables: per 32-sphere block 64 floats (lane l: k = l/32 of sphere l%32)
+    const int padded64 = (n + 63) / 64 * 64, image = 2 * padded64;
+    float *l_axy = (float *)(l_cull_dir + nd * cull.padded), *l_azk = l_axy + image, *l_azk_dir = l_azk + image;
+    for (int i = threadIdx.x; i < (TRT_SWEEP_MFMA ? (1 + nd) * image : 0); i += blockDim.x)
+    {
+        const int which = i / image, j = i - which * image; // which: 0 generic table, 1 + li fixed direction of light li
+        const int lane_ = j & 63, sphere = (j >> 6) * 32 + (lane_ & 31);
+        float4 e = float4{0.0f, 0.0f, 0.0f, TRT_CULL_PAD_KK};
+        if (sphere < cull.padded)
+            e = which == 0 ? l_cull[sphere] : l_cull_dir[(which - 1) * cull.padded + sphere];
+        if (which == 0)
+        {
+            l_axy[j] = lane_ < 32 ? e.x : e.y;
+            l_azk[j] = lane_ < 32 ? e.z : e.w;
+        }
+        else
+            l_azk_dir[(which - 1) * image + j] = lane_ < 32 ? e.z : e.w;
+    }
     __syncthreads();
-    return LdsImage{l_cull, l_cull_dir, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit};
+    return LdsImage{l_cull, l_cull_dir, l_axy, l_azk, l_azk_dir, padded64, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit};
 }
 
 struct Hit
@@ -110,14 +144,95 @@ struct Hit
     int i;     // -1: nothing; [0,n): sphere; n: ground
 };
 
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// v_permlane32_swap a, b:  a <- [a.lo32, b.lo32],  b <- [a.hi32, b.hi32]   (lo32 = lanes 0-31).  Through inline asm:
+// hipcc (ROCm 7.2) folds MFMAs fed by the two results of __builtin_amdgcn_permlane32_swap into one (tools/mfma_probe).
+// The s_nops cover the data hazards around it (VALU result -> permlane read, permlane result -> MFMA/VALU read):
+// the compiler's hazard recogniser cannot look inside the asm statement (cdna_hip_programming.md 5.7).
+TRT_DEV void lane_swap32(float &a, float &b)
+{
+    asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(a), "+v"(b));
+}
+
+// Phase 1 for one chunk of 64 spheres and the 64 rays of the wave, on the MATRIX cores.
+// The culling test is a small dense contraction: for sphere row j and ray column i (K = 4)
+//     cd[j][i] = (Cx,Cy,Cz,kk) . (dx,dy,dz, 0)              cw[j][i] = (Cx,Cy,Cz,kk) . (wx,wy,wz,-1) - thr_i
+// and the verdict is the sign of fma(cd,cd,cw) (trt_filter.h).  v_mfma_f32_32x32x2_f32 evaluates exactly that FMA chain
+// (k = 0..3, FP32, checked bit for bit against fmaf by tools/mfma_probe), on a pipe of its own, so the VALU is left with
+// one FMA and one v_alignbit per (ray, sphere) -- v_alignbit alone for a fixed direction, whose cd^2 is in the table.
+// Tiles: 2 blocks of 32 spheres x 2 blocks of 32 rays.  A operand of a sphere block: lane l holds A[l%32][k = l/32];
+// B operand of a ray block: lane l holds B[k = l/32][l%32], made from the per-lane ray constants with one
+// v_permlane32_swap per pair; D: lane l holds ray l%32 and, in register v, sphere row (v/4)*8 + (l/32)*4 + v%4.
+// Returns, for THIS lane's ray, two 32-bit words (rows held by lanes < 32 / >= 32): bit 31-p of word h set = candidate
+// sphere 32*(p>>4) + ((p&15)>>2)*8 + 4*h + (p&3) of the chunk.
+template <bool FIXED>
+TRT_DEV void sweep64_mfma(const float *a_xy, const float *a_zk, int lane, const trt_ray_filter &f, unsigned &half0, unsigned &half1)
+{
+    const float axy[2] = {a_xy[lane], a_xy[64 + lane]}, azk[2] = {a_zk[lane], a_zk[64 + lane]};
+    float wxy[2] = {f.wx, f.wy}, wz1[2] = {f.wz, -1.0f}, thr[2] = {f.neg_thr, f.neg_thr};
+    lane_swap32(wxy[0], wxy[1]);
+    lane_swap32(wz1[0], wz1[1]);
+    lane_swap32(thr[0], thr[1]); // thr[r] = -thr of ray l%32 + 32r in every lane
+    float dxy[2] = {f.dx, f.dy}, dz0[2] = {f.dz, 0.0f};
+    if (!FIXED)
+    {
+        lane_swap32(dxy[0], dxy[1]);
+        lane_swap32(dz0[0], dz0[1]);
+    }
+    float word[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+    {
+        unsigned bits = ~0u;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+        {
+            f16v cw;
+#pragma unroll
+            for (int v = 0; v < 16; v++)
+                cw[v] = thr[r];
+            cw = __builtin_amdgcn_mfma_f32_32x32x2f32(axy[s], wxy[r], cw, 0, 0, 0);
+            cw = __builtin_amdgcn_mfma_f32_32x32x2f32(azk[s], wz1[r], cw, 0, 0, 0);
+            if (!FIXED)
+            {
+                f16v cd = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                cd = __builtin_amdgcn_mfma_f32_32x32x2f32(axy[s], dxy[r], cd, 0, 0, 0);
+                cd = __builtin_amdgcn_mfma_f32_32x32x2f32(azk[s], dz0[r], cd, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 16; v++)
+                {
+                    const float m = __builtin_fmaf(cd[v], cd[v], cw[v]);
+                    bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(unsigned, m), 31);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int v = 0; v < 16; v++)
+                {
+                    const float m = cw[v]; // NB: __builtin_bit_cast applied to the element lvalue cw[v] itself reads element 0
+                    bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(unsigned, m), 31);
+                }
+            }
+        }
+        word[r] = __builtin_bit_cast(float, ~bits); // set = candidate
+    }
+    lane_swap32(word[0], word[1]); // both halves of the rows of this lane's own ray
+    half0 = __builtin_bit_cast(unsigned, word[0]);
+    half1 = __builtin_bit_cast(unsigned, word[1]);
+}
+
 // Closest hit of TRT.c:793-856 for the lanes with `active`.  ANY_HIT: the caller only asks whether anything
 // is hit (directional-light shadow ray, TRT.c:908), so a lane stops at its first hit and the ground is skipped
-// once a sphere was found.
-// `fixed` != nullptr: all rays of this call share the direction the table was built for (directional light).
+// once a sphere was found.  `a_zk_fixed` != nullptr: all rays share the direction that table was built for.
 template <bool ANY_HIT>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
-                  const float4 *fixed = nullptr)
+                  int lane, const float4 *fixed = nullptr, const float *a_zk_fixed = nullptr)
 {
+    (void)lane;
+    (void)fixed;
+    (void)a_zk_fixed;
     Hit best;
     best.d2 = __builtin_inf();
     best.p = o;
@@ -126,6 +241,59 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     trt_ray_filter flt;
     trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
 
+#if TRT_SWEEP_MFMA
+    for (int base = 0; base < L.padded64; base += 64)
+    {
+        // phase 1 on the matrix cores (all 64 lanes take part: the tiles hold every lane's column)
+        unsigned half[2];
+        if (ANY_HIT && a_zk_fixed)
+            sweep64_mfma<true>(L.a_xy + 2 * base, a_zk_fixed + 2 * base, lane, flt, half[0], half[1]);
+        else
+            sweep64_mfma<false>(L.a_xy + 2 * base, L.a_zk + 2 * base, lane, flt, half[0], half[1]);
+        if (!flt.ok)
+            half[0] = half[1] = ~0u; // degenerate ray: every sphere of the chunk goes to the exact test
+        if (!active)
+            half[0] = half[1] = 0u;
+        // phase 2: exact FP64 tests of this lane's candidates.  The words are not in sphere order, so the tie rule of
+        // TRT.c:816 (strict '<': the lowest index wins among equal distances) is applied explicitly.
+        while (__any((half[0] | half[1]) != 0))
+        {
+            phase2_rounds++;
+            if ((half[0] | half[1]) != 0)
+            {
+                const int h = half[0] != 0 ? 0 : 1;
+                const int p = __builtin_clz(half[h]);
+                half[h] &= ~(0x80000000u >> p);
+                const int i = base + ((p >> 4) << 5) + (((p & 15) >> 2) << 3) + (h << 2) + (p & 3);
+                if (i < n)
+                {
+                    const d3 c = d3{L.cx[i], L.cy[i], L.cz[i]};
+                    const d3 oc = sub(o, c);
+                    const double b = 2.0 * dot(oc, d);
+                    const double cc = dot(oc, oc) - L.r2[i];
+                    const double disc = b * b - 4.0 * a * cc;
+                    if (!(disc < 0.0))
+                    {
+                        const double t0 = (-b - __builtin_sqrt(disc)) / (2.0 * a);
+                        if (t0 > 0.0)
+                        {
+                            const d3 pt = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
+                            const double d2 = dist2(o, pt);
+                            if (d2 < best.d2 || (d2 == best.d2 && i < best.i))
+                            {
+                                best.d2 = d2;
+                                best.p = pt;
+                                best.i = i;
+                            }
+                            if (ANY_HIT)
+                                half[0] = half[1] = 0u;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#else
     for (int base = 0; base < cull.padded; base += 64)
     {
         // phase 1: wave-uniform sweep; each verdict is a sign bit shifted into a per-lane word by v_alignbit,
@@ -198,6 +366,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
             }
         }
     }
+#endif
     // ground plane (TRT.c:831-853)
     if (active && !(ANY_HIT && best.i >= 0))
     {
@@ -318,7 +487,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
         if (COUNT && alive)
             n_path++;
         TRT_STAMP_AT(1); // unit(next_dir)
-        const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2);
+        const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2, lane);
         TRT_STAMP_AT(2); // P trace
         const bool path_hit = alive && ph.i >= 0, path_sky = alive && ph.i < 0;
 
@@ -367,7 +536,8 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
                 { // directional light, TRT.c:900-923
                     sd = load3(L.dir + li * 6);
                     lcolor = load3(L.dir + li * 6 + 3);
-                    const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, L.cull_dir + li * cull.padded);
+                    const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, L.cull_dir + li * cull.padded,
+                                               L.a_zk_dir + li * 2 * L.padded64);
                     is_lit = sh.i < 0;
                     factor = min1(dot(h_normal, sd));
                     TRT_STAMP_AT(4); // directional shadow
@@ -380,7 +550,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
                     const double strength = clampd(pl[6] / light_d2, 0.0, 1.0);
                     sd = unit(to_light);
                     lcolor = load3(pl + 3);
-                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2);
+                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane);
                     is_lit = sh.i < 0;
                     if (__any(path_hit && sh.i >= 0))
                     { // a blocker: is it farther than the light?  distance to the NUDGED blocker point, TRT.c:939-942

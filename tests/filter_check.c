@@ -32,6 +32,9 @@ static int exact_hit(const double *o, const double *d, double a, const double *s
     return t0 > 0.0 ? 2 : 1; /* 2 = hit, 1 = line intersects but not ahead */
 }
 
+/* 0: the VALU sweep's operation order (trt_filter_sign); 1: the MFMA sweep's order (trt_filter_sign_mfma) */
+int g_filter_order = 0;
+
 void filter_check(const double *spheres, int n, const double *rays, size_t n_rays, filter_stats *st)
 {
     memset(st, 0, sizeof *st);
@@ -49,7 +52,8 @@ void filter_check(const double *spheres, int n, const double *rays, size_t n_ray
         unsigned cand = 0, hits = 0;
         for (int i = 0; i < padded; i++)
         {
-            const int pass = trt_filter_pass(&f, table[4 * i], table[4 * i + 1], table[4 * i + 2], table[4 * i + 3]);
+            const int pass = g_filter_order == 0 ? trt_filter_pass(&f, table[4 * i], table[4 * i + 1], table[4 * i + 2], table[4 * i + 3])
+                                                 : (!f.ok || !(trt_filter_sign_mfma(&f, table[4 * i], table[4 * i + 1], table[4 * i + 2], table[4 * i + 3]) >> 31));
             if (i >= n)
             {
                 if (pass)
@@ -112,7 +116,9 @@ void filter_check_fixed_dir(const double *spheres, int n, const double *rays, si
         unsigned cand = 0, hits = 0;
         for (int i = 0; i < n; i++)
         {
-            const int pass = !f.ok || !(trt_filter_sign_fixed_dir(&f, table[4 * i], table[4 * i + 1], table[4 * i + 2], table[4 * i + 3]) >> 31);
+            const unsigned sgn = g_filter_order == 0 ? trt_filter_sign_fixed_dir(&f, table[4 * i], table[4 * i + 1], table[4 * i + 2], table[4 * i + 3])
+                                                     : trt_filter_sign_fixed_dir_mfma(&f, table[4 * i], table[4 * i + 1], table[4 * i + 2], table[4 * i + 3]);
+            const int pass = !f.ok || !(sgn >> 31);
             double disc;
             const int e = exact_hit(o, d, a, spheres + 9 * i, &disc);
             st->pairs++;

@@ -43,6 +43,15 @@ def checker():
     return lib
 
 
+@pytest.fixture(params=[0, 1], ids=["valu_order", "mfma_order"], autouse=True)
+def operation_order(request, checker):
+    """Every test runs for both evaluation orders of the sweep: the VALU form (default build) and the
+    FMA-chain order of the matrix-core form (-DTRT_SWEEP_MFMA=1)."""
+    C.c_int.in_dll(checker, "g_filter_order").value = request.param
+    yield
+    C.c_int.in_dll(checker, "g_filter_order").value = 0
+
+
 def run(checker, spheres, rays):
     spheres = np.ascontiguousarray(spheres, dtype=np.float64).reshape(-1, 9)
     rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
