@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=0, help="0 production, 1 reference-order (debug)")
     ap.add_argument("--units", type=int, default=0, help="work units of the production kernel: 0 auto, 1 pixels, 2 samples")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
     ap.add_argument("--depth", type=int, default=2, help="frames in flight per GPU (1 = strictly one frame at a time)")
     args = ap.parse_args()
 
@@ -108,8 +110,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    local = local % max(1, torch.cuda.device_count())  # rehearsals may put several ranks on one GPU
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local)
 
     scene = build_scene()
@@ -135,6 +141,20 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.check:  # the sharded, gathered frame must equal the frame of one renderer, bit for bit
+        frame = r.render(scene.camera)
+        torch.cuda.synchronize()
+        if rank == 0:
+            with hip.Context(local) as single:
+                single.set_scene(scene)
+                whole = single.render_host(scene.camera, hip.RowSet.whole(W, H), BOUNCES, SPP)
+            same = np.array_equal(frame.cpu().numpy().view(np.uint64), whole.view(np.uint64))
+            print(f"CHECK sharded({world}) == single: {same}", file=sys.stderr)
+            assert same
+        for _ in range(args.depth - 1):
+            r.render(scene.camera)
+        barrier()
 
     for _ in range(args.warmup):
         r.render(scene.camera)

@@ -56,9 +56,19 @@ class ShardedFrame:
         Returns the (H, W, 3) frame on the root, None elsewhere."""
         if self.world == 1:
             return self.shard[: self.height]  # a single renderer's rows are already in frame order
-        dist.gather(self.shard, self.gathered if self.rank == self.root else None, dst=self.root)
-        if self.rank != self.root:
-            return None
+        if self.shard.is_cuda and dist.get_backend() == "gloo":
+            # rehearsal path only (several ranks sharing one GPU, where RCCL cannot be used): stage through the host
+            host = self.shard.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.root else None
+            dist.gather(host, parts, dst=self.root)
+            if self.rank != self.root:
+                return None
+            for dst, src in zip(self.gathered, parts):
+                dst.copy_(src)
+        else:
+            dist.gather(self.shard, self.gathered if self.rank == self.root else None, dst=self.root)
+            if self.rank != self.root:
+                return None
         torch.index_select(torch.cat(self.gathered, dim=0), 0, self.take, out=self.frame)
         return self.frame
 

@@ -238,3 +238,42 @@ def test_c_demo_driver_runs_the_reference_frame_loop(tmp_path):
     assert b"3 frames 160x48" in out.stderr
     # three full emitter buffers went to stdout: 8 + (25*160+1)*48 + 1 bytes each plus the fps lines
     assert out.stdout.count(b"\033[48;2;") == 3 * 160 * 48
+
+
+@pytest.mark.parametrize("w,h,n,b", [(3840, 2160, 64, 8), (1920, 1080, 256, 12), (1920, 1080, 8, 4)],
+                         ids=["config4_2160p_64sph_b8", "config5_1080p_256sph_b12", "config2_1080p_8sph_b4"])
+def test_baseline_configs_at_full_size(ctx, w, h, n, b):
+    """BASELINE configs 2, 4, 5 at their full sizes: the production kernel equals the reference-order kernel bit for
+    bit (two independent implementations), a band equals the CPU oracle, and the trace_ray counts of the two agree."""
+    scene = S.synth_scene(n, S.synth_sky(256), T.bench_camera(w, h), seed=1234)
+    ctx.enable_counters(True)
+    try:
+        fast = render(ctx, scene, w, h, b, 10, KERNELS[0])
+        fast_counts = ctx.read_counters()
+        slow = render(ctx, scene, w, h, b, 10, KERNELS[3])
+        slow_counts = ctx.read_counters()
+    finally:
+        ctx.enable_counters(False)
+    assert np.array_equal(bits(fast), bits(slow))
+    assert fast_counts == slow_counts and fast_counts[0] > w * h * 10
+    r0 = h // 2 - 4
+    band, _ = T.oracle_render(scene, w, h, b, 10, rows=(r0, r0 + 8))
+    assert np.array_equal(bits(fast[r0:r0 + 8]), bits(band))
+
+
+def test_orbit_animation_frames_match_oracle(ctx):
+    """Config 5's moving camera: frames at several orbit times, pipelined over two contexts like the bench does."""
+    from terminalraytracer_amd.distributed import HipShardRenderer
+    import torch
+    w, h = 240, 135
+    scene = S.synth_scene(64, S.synth_sky(64), T.bench_camera(w, h), seed=1234)
+    r = HipShardRenderer(scene, w, h, 0, 1, 0, 8, 10, depth=2)
+    try:
+        for t in (0.0, 0.5, 2.5, 10.0, 33.3):
+            cam = T.bench_camera(w, h, t)
+            frame = r.render(cam).clone()
+            torch.cuda.synchronize()
+            want, _ = T.oracle_render(scene.with_camera(cam), w, h, 8, 10)
+            assert np.array_equal(bits(frame.cpu().numpy()), bits(want)), t
+    finally:
+        r.close()
