@@ -272,7 +272,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
                     const double b = 2.0 * dot(oc, d);
                     const double cc = dot(oc, oc) - L.r2[i];
                     const double disc = b * b - 4.0 * a * cc;
-                    if (!(disc < 0.0))
+                    if (!(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
                     {
                         const double t0 = (-b - __builtin_sqrt(disc)) / (2.0 * a);
                         if (t0 > 0.0)
@@ -345,7 +345,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
                     const double b = 2.0 * dot(oc, d);
                     const double cc = dot(oc, oc) - L.r2[i];
                     const double disc = b * b - 4.0 * a * cc;
-                    if (!(disc < 0.0))
+                    if (!(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
                     {
                         const double t0 = (-b - __builtin_sqrt(disc)) / (2.0 * a);
                         if (t0 > 0.0)
@@ -552,10 +552,20 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
                     lcolor = load3(pl + 3);
                     const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane);
                     is_lit = sh.i < 0;
-                    if (__any(path_hit && sh.i >= 0))
-                    { // a blocker: is it farther than the light?  distance to the NUDGED blocker point, TRT.c:939-942
+                    // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the
+                    // blocker point NUDGED 1e-6 back along the ray (TRT.c:871-874, :939-942): (D - 1e-6)^2 up to ~1e-14 relative
+                    // rounding, where D^2 = sh.d2 (1 +- 4u).  From D <= (D^2+1)/2:
+                    //     (D-1e-6)^2 (1-1e-14)  >=  sh.d2 (1 - 1.01e-6) - 1.01e-6      and, for D >= 1e-5,   (D-1e-6)^2 (1+1e-14) < sh.d2.
+                    // Outside that band the answer is certain without normalising anything; inside it (about one ray in 1e5)
+                    // the exact nudged point is formed as the reference does.
+                    const bool surely_lit = light_d2 < sh.d2 * (1.0 - 1.01e-6) - 1.01e-6;
+                    const bool surely_dark = sh.d2 > 1e-10 && light_d2 >= sh.d2;
+                    if (sh.i >= 0)
+                        is_lit = surely_lit;
+                    if (__any(path_hit && sh.i >= 0 && !surely_lit && !surely_dark))
+                    {
                         const d3 to_blocker = sub(add(sh.p, scale(unit(sub(o, sh.p)), 0.000001)), o);
-                        if (sh.i >= 0)
+                        if (sh.i >= 0 && !surely_lit && !surely_dark)
                             is_lit = light_d2 < dot(to_blocker, to_blocker);
                     }
                     factor = strength * min1(dot(h_normal, sd));

@@ -277,3 +277,24 @@ def test_orbit_animation_frames_match_oracle(ctx):
             assert np.array_equal(bits(frame.cpu().numpy()), bits(want)), t
     finally:
         r.close()
+
+
+def test_point_light_at_blocker_distance_forces_the_exact_branch(ctx):
+    """The rounds kernel decides "is the blocker farther than the light?" (TRT.c:939-942) from bounds and forms the exact
+    nudged blocker point only in a band of relative width ~1e-6.  Lights sitting on / within micrometres of a sphere's
+    surface put whole regions of the image inside and just outside that band (both sides), the blocker being the very
+    sphere the light touches; every kernel must still equal the oracle bit for bit."""
+    w, h = 96, 54
+    base = S.demo_scene(T.sky("synth"), T.bench_camera(w, h))
+    centre, radius = base.spheres[4, :3], base.spheres[4, 3]  # the sphere at (0,-1,0), just above the ground
+    lights = []
+    for k, eps in enumerate([0.0, 1e-6, -1e-6, 2e-6, -2e-6, 1.0000001e-6, 0.5e-6, -0.5e-6, 1e-5, -1e-5]):
+        n = np.array([np.cos(0.7 * k), -0.8, np.sin(0.7 * k)])
+        n /= np.linalg.norm(n)
+        lights.append(list(centre + n * (radius + eps)) + [1.0, 0.9, 0.8, 3.0])
+    scene = S.SceneData(base.spheres, base.ground, base.dir_lights, np.array(lights), base.camera, base.sky)
+    want, st = T.oracle_render(scene, w, h, 4, 10)
+    assert st.shadow_rays > 10 * st.path_rays * 0.5  # eleven lights per hit
+    for kernel in KERNELS:
+        got = render(ctx, scene, w, h, 4, 10, kernel)
+        assert np.array_equal(bits(got), bits(want)), kernel
