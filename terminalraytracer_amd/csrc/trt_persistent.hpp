@@ -78,7 +78,10 @@ constexpr int kPersistentBlock = 256;
 #define TRT_PERSISTENT_WAVES 4 // min waves per SIMD the register allocator must leave room for (= 256-thread blocks per CU)
 #endif
 constexpr unsigned kQueueChunkPixels = 64;   // work units fetched from the global queue per atomic (one wave's worth)
-constexpr unsigned kQueueChunkSamples = 256;
+#ifndef TRT_QUEUE_CHUNK
+#define TRT_QUEUE_CHUNK 256
+#endif
+constexpr unsigned kQueueChunkSamples = TRT_QUEUE_CHUNK;
 constexpr int kCullGroup = 8;  // culling-table entries fetched per scalar-load batch (table padded to this)
 
 struct PersistentLaunch

@@ -350,16 +350,22 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
                         const double t0 = (-b - __builtin_sqrt(disc)) / (2.0 * a);
                         if (t0 > 0.0)
                         {
-                            const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
-                            const double d2 = dist2(o, p);
-                            if (d2 < best.d2)
-                            {
-                                best.d2 = d2;
-                                best.p = p;
-                                best.i = i;
-                            }
                             if (ANY_HIT)
+                            { // "anything in the way?" (TRT.c:908): the first hit answers it; its position is never used
+                                best.i = i;
                                 cand = 0;
+                            }
+                            else
+                            {
+                                const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
+                                const double d2 = dist2(o, p);
+                                if (d2 < best.d2)
+                                {
+                                    best.d2 = d2;
+                                    best.p = p;
+                                    best.i = i;
+                                }
+                            }
                         }
                     }
                 }
@@ -373,12 +379,17 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         d3 p;
         if (hit_plane(o, d, gp, gn, p))
         {
-            const double d2 = dist2(o, p);
-            if (d2 < best.d2)
+            if (ANY_HIT)
+                best.i = n; // nothing closer can matter: any hit blocks the light
+            else
             {
-                best.d2 = d2;
-                best.p = p;
-                best.i = n;
+                const double d2 = dist2(o, p);
+                if (d2 < best.d2)
+                {
+                    best.d2 = d2;
+                    best.p = p;
+                    best.i = n;
+                }
             }
         }
     }

@@ -298,3 +298,22 @@ def test_point_light_at_blocker_distance_forces_the_exact_branch(ctx):
     for kernel in KERNELS:
         got = render(ctx, scene, w, h, 4, 10, kernel)
         assert np.array_equal(bits(got), bits(want)), kernel
+
+
+@pytest.mark.parametrize("w,h,n,b,spp", [(33, 17, 6, 1, 10), (64, 36, 64, 3, 1), (50, 20, 17, 5, 7), (40, 12, 64, 8, 64),
+                                           (257, 3, 100, 4, 10), (3, 257, 33, 2, 5)])
+def test_odd_parameters_against_the_oracle(ctx, w, h, n, b, spp):
+    """No goldens here: the oracle (itself pinned to the reference) is the checker.  Bounce limit 1, one and many
+    rays per pixel (more than a wave's worth of samples per pixel), sphere counts that are not multiples of 8/32/64,
+    frames narrower than a wave."""
+    spheres = S.demo_spheres() if n == 6 else S.synth_spheres(n, seed=99)
+    scene = S.synth_scene(n, T.sky("synth"), T.bench_camera(w, h, 2.5), seed=99).with_spheres(spheres)
+    want, st = T.oracle_render(scene, w, h, b, spp)
+    ctx.enable_counters(True)
+    try:
+        for kernel in KERNELS:
+            got = render(ctx, scene, w, h, b, spp, kernel)
+            assert np.array_equal(bits(got), bits(want)), kernel
+            assert ctx.read_counters() == (st.path_rays, st.shadow_rays), kernel
+    finally:
+        ctx.enable_counters(False)
