@@ -1,4 +1,7 @@
-// trt_persistent.hpp -- production frame-producer kernel for gfx950.
+// trt_persistent.hpp -- the EARLIER production design (kernel id 2): persistent waves with a per-lane state machine.
+// Superseded by the mode-synchronous rounds of trt_rounds.hpp (kernel id 0), kept as an independent implementation for
+// parity tests and A/B measurements; it also hosts what both share: LDS sizing, the work-queue constants, the ordered
+// reduction kernel and the TRT_DUP / TRT_STAMP cost-attribution switches.
 //
 // Shape of the work: per pixel `spp` samples, per sample a bounce loop, per bounce
 // one closest-hit trace plus one shadow trace per light; a trace = N sphere tests + 1 plane test.

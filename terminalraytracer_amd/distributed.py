@@ -29,18 +29,23 @@ def shard_rows(width, height, rank, world, tile_rows):
 class ShardedFrame:
     """Owns the shard buffer of this rank, the gather buffers and the row permutation on the root."""
 
-    def __init__(self, width, height, rank, world, device, tile_rows=8, root=0):
+    def __init__(self, width, height, rank, world, device, tile_rows=8, root=0, dtype=torch.float64):
+        """dtype float64: the reference's Screen layout (3 doubles per pixel, TerminalRayTracer.c:188-193);
+        uint8: the (int)(c*255) bytes the emitter prints (TerminalRayTracer.c:1157-1163), 8x less to gather."""
         self.width, self.height, self.rank, self.world, self.root = width, height, rank, world, root
         self.device = torch.device(device)
+        self.dtype = dtype
         self.rowset = hip.RowSet.shard(width, height, rank, world, tile_rows)
         per_rank = [shard_rows(width, height, r, world, tile_rows) for r in range(world)]
         self.local_rows = len(per_rank[rank])
         self.max_rows = max(len(r) for r in per_rank)  # shards are padded to equal size for the gather
-        self.shard = torch.zeros((self.max_rows, width, 3), dtype=torch.float64, device=self.device)
+        self.shard = torch.zeros((self.max_rows, width, 3), dtype=dtype, device=self.device)
         self.frame = None
         self.gathered = None
         if rank == root:
-            self.gathered = [torch.zeros_like(self.shard) for _ in range(world)] if world > 1 else None
+            # one contiguous buffer, the gather list is views into it: no concatenation per frame
+            self.gathered_all = torch.zeros((world * self.max_rows, width, 3), dtype=dtype, device=self.device) if world > 1 else None
+            self.gathered = list(self.gathered_all.split(self.max_rows, dim=0)) if world > 1 else None
             # row index in the concatenated (padded) gather buffer -> frame row
             src, dst = [], []
             for r, rows in enumerate(per_rank):
@@ -49,7 +54,7 @@ class ShardedFrame:
             order = np.argsort(dst)
             assert sorted(dst) == list(range(height))
             self.take = torch.tensor(np.asarray(src)[order], dtype=torch.long, device=self.device)
-            self.frame = torch.zeros((height, width, 3), dtype=torch.float64, device=self.device)
+            self.frame = torch.zeros((height, width, 3), dtype=dtype, device=self.device)
 
     def assemble(self):
         """Collective: gather every rank's shard to the root and put the rows in frame order.
@@ -69,7 +74,7 @@ class ShardedFrame:
             dist.gather(self.shard, self.gathered if self.rank == self.root else None, dst=self.root)
             if self.rank != self.root:
                 return None
-        torch.index_select(torch.cat(self.gathered, dim=0), 0, self.take, out=self.frame)
+        torch.index_select(self.gathered_all, 0, self.take, out=self.frame)
         return self.frame
 
 
@@ -85,17 +90,22 @@ class HipShardRenderer:
     is overwritten `depth` calls later."""
 
     def __init__(self, scene_data, width, height, rank, world, local_device, bounce_limit, rays_per_pixel,
-                 tile_rows=8, depth=2):
+                 tile_rows=8, depth=2, rgb8=False):
+        """rgb8=True: every rank quantises its shard on the device (trt_quantize_device) and the 3-byte pixels are
+        gathered instead of the doubles -- all a terminal emitter needs, and bit-exact for it."""
         torch.cuda.set_device(local_device)
         self.bounce_limit, self.rays_per_pixel = bounce_limit, rays_per_pixel
+        self.rgb8 = rgb8
         self.slots = []
         for _ in range(max(1, depth)):
             ctx = hip.Context(local_device)
             ctx.set_scene(scene_data)
             stream = torch.cuda.Stream(device=local_device)
             ctx.set_stream(stream.cuda_stream)
-            self.slots.append({"ctx": ctx, "stream": stream,
-                               "frame": ShardedFrame(width, height, rank, world, f"cuda:{local_device}", tile_rows),
+            frame = ShardedFrame(width, height, rank, world, f"cuda:{local_device}", tile_rows,
+                                 dtype=torch.uint8 if rgb8 else torch.float64)
+            self.slots.append({"ctx": ctx, "stream": stream, "frame": frame,
+                               "pixels": torch.zeros((frame.max_rows, width, 3), dtype=torch.float64, device=f"cuda:{local_device}") if rgb8 else frame.shard,
                                "rendered": torch.cuda.Event(), "consumed": torch.cuda.Event()})
         self.calls = 0
         self.ctx = self.slots[0]["ctx"]          # for counters / kernel selection helpers
@@ -112,8 +122,10 @@ class HipShardRenderer:
             slot["stream"].wait_event(slot["consumed"])  # the previous frame of this slot has been assembled
         self.calls += 1
         s = slot["frame"]
-        slot["ctx"].render_device(camera, s.rowset, self.bounce_limit, self.rays_per_pixel, s.shard.data_ptr(),
-                                  s.shard.numel() * 8)
+        px = slot["pixels"]
+        slot["ctx"].render_device(camera, s.rowset, self.bounce_limit, self.rays_per_pixel, px.data_ptr(), px.numel() * 8)
+        if self.rgb8:
+            slot["ctx"].quantize_device(px.data_ptr(), s.local_rows * s.width, s.shard.data_ptr())
         slot["rendered"].record(slot["stream"])
         main.wait_event(slot["rendered"])
         frame = s.assemble()

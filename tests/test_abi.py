@@ -52,3 +52,16 @@ def test_rowset_rejects_nonsense():
                 hip.RowSet(10, 10, 1, 0, 0)):
         assert lib.trt_rowset_rows(C.byref(bad)) == 0
     assert lib.trt_rowset_rows(None) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """There is no CPU or PyTorch fallback: without libtrt_hip.so the binding raises, it does not degrade."""
+    hip.lib.cache_clear()
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "libtrt_hip.so"))
+    try:
+        with pytest.raises(ImportError, match="no fallback"):
+            hip.lib()
+    finally:
+        monkeypatch.undo()
+        hip.lib.cache_clear()
+        hip.lib()

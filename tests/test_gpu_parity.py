@@ -367,3 +367,25 @@ def test_fuzzed_scenes_match_the_oracle(ctx, seed):
             assert np.array_equal(bits(got), bits(want)), (seed, kernel)
         else:  # NaNs (e.g. a camera exactly on a light) must at least sit in the same pixels with equal finite neighbours
             assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(bits(got[np.isfinite(want)]), bits(want[np.isfinite(want)]))
+
+
+def test_rgb8_sharded_renderer_feeds_the_emitter(ctx):
+    """SURVEY f-3: quantise on the device, move 3 bytes per pixel, patch the emitter on the host."""
+    import zlib
+    import torch
+    from terminalraytracer_amd import host
+    from terminalraytracer_amd.distributed import HipShardRenderer
+    case = next(c for c in SMALL if c["name"] == "demo_160x48_b4")
+    scene = T.golden_scene(case)
+    r = HipShardRenderer(scene, 160, 48, 0, 1, 0, 4, 10, depth=2, rgb8=True)
+    try:
+        for _ in range(3):
+            frame = r.render(scene.camera)
+        torch.cuda.synchronize()
+        rgb = frame.cpu().numpy()
+    finally:
+        r.close()
+    assert rgb.dtype == np.uint8 and T.fnv(rgb) == case["rgb8_fnv"]
+    em = host.Emitter(160, 48)
+    em.patch_rgb8(rgb)
+    assert em.bytes() == zlib.decompress(open(T.GOLDEN + "/emit_demo_160x48_b4.bin.z", "rb").read())
