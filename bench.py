@@ -202,7 +202,12 @@ def main():
                           "peak_tflops_no_fma": FP64_PEAK_TFLOPS / 2,
                           "note": "reference op count 25*N+17 per trace; the kernel does fewer ops than that (FP32 culling)"},
             "kernel_info": r.ctx.kernel_info(),
-            "diagnostics": dict(diag, lane_utilisation=(path_rays + shadow_rays) / max(1, 64 * diag["wave_loop_trips"])),
+            # rounds kernel (id 0): one round = one path ray per lane (+ one shadow ray per light for the lanes that hit something)
+            "diagnostics": dict(diag, path_lane_utilisation=path_rays / max(1, 64 * diag["wave_loop_trips"]),
+                                shadow_lane_utilisation=shadow_rays / max(1, 64 * diag["wave_loop_trips"] * max(1, scene.dir_lights.shape[0] + scene.point_lights.shape[0])),
+                                exact_test_rounds_per_trace=diag["phase2_rounds"] / max(1, path_rays + shadow_rays) * 64)
+            if args.kernel == 0 and args.units != 1 else
+            dict(diag, lane_utilisation=(path_rays + shadow_rays) / max(1, 64 * diag["wave_loop_trips"])),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene)
