@@ -26,7 +26,10 @@ $(BUILD)/host_%.o: $(CSRC)/host/%.c include/trt.h include/trt_host.h
 
 $(BUILD)/trt_capi$(subst =,_,$(subst -D,_,$(TUNE))).o: $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/trt_capi.hip
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o $@ $(CSRC)/trt_capi.hip 2> $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt \
+		|| (cat $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt; false)
+	@grep -E "error|warning:" $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt || true
+	@awk '/Function Name: .*render_rounds_kernelILb0/ {f=1} f && /VGPRs:/ {split($$0,a,"VGPRs: "); v=a[2]+0; print "render_rounds_kernel<false>: " v " VGPRs" (v>128 ? "  ** WARNING: more than 128 -> 3 waves/SIMD **" : " (4 waves/SIMD)"); exit}' $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt
 
 $(LIB): $(BUILD)/trt_capi$(subst =,_,$(subst -D,_,$(TUNE))).o $(HOST_OBJ)
 	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $< $(HOST_OBJ)

@@ -396,8 +396,15 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     return best;
 }
 
+// Register budget: asking the allocator for only 3 waves/SIMD lets it settle at 127 VGPRs -- which still runs 4 waves/SIMD
+// (<= 128) -- with a better schedule than when it is forced under 128 (measured 3.02 vs 3.15 ms).  The build records the
+// compiler's resource report in build/resource_usage.txt and `make lib` warns if this kernel ever needs more than 128.
+#ifndef TRT_ROUNDS_WAVES
+#define TRT_ROUNDS_WAVES 3
+#endif
+
 template <bool COUNT>
-__global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f)
+__global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const LdsImage L = stage_lds_image(lds, s, cull, f);
@@ -410,7 +417,6 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
     // ---- per-lane state ------------------------------------------------------------------------------
     bool alive = true;             // owns a unit (a sample being traced)
     bool want_unit = true;         // needs a (new) unit before the next round
-    unsigned unit_id = 0;          // pixel*spp + k
     unsigned slot_id = 0;          // k*pixels + pixel: where the sample's colour goes in f.samples
     d3 sample = d3{0.0, 0.0, 0.0}; // pixel_color of the sample (TRT.c:1012)
     double weight = 1.0, weight_sum = 0.0;
@@ -455,7 +461,6 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_PERSISTENT_WAVES) void render
                     alive = mine < total;
                     if (alive)
                     {
-                        unit_id = mine;
                         // unit -> (pixel, k) -> (row, column) by multiply-high with min(ceil(2^32/x), 2^32-1): off by at most one
                         unsigned pixel = __umulhi(mine, f.spp_magic);
                         int k = (int)(mine - pixel * (unsigned)f.spp);
