@@ -85,7 +85,10 @@ constexpr unsigned kQueueChunkPixels = 64;   // work units fetched from the glob
 #define TRT_QUEUE_CHUNK 256
 #endif
 constexpr unsigned kQueueChunkSamples = TRT_QUEUE_CHUNK;
-constexpr int kCullGroup = 8;  // culling-table entries fetched per scalar-load batch (table padded to this)
+#ifndef TRT_CULL_GROUP
+#define TRT_CULL_GROUP 8
+#endif
+constexpr int kCullGroup = TRT_CULL_GROUP; // culling-table entries fetched per scalar-load batch (table padded to this)
 
 struct PersistentLaunch
 {
