@@ -11,6 +11,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "trt_device.hpp"
@@ -107,6 +109,8 @@ struct trt_context
 
     int kernel = 0; // 0 production (synchronous rounds), 1 reference-order, 2 per-lane state machine
     int rounds_blocks_per_cu = 0;
+    size_t occupancy_for_lds = (size_t)-1;
+    hipEvent_t ev_chunk[16]; // hand-over of framebuffer chunks to the host copy threads (trt_render_host)
     int units = 0;  // work units of the production kernel: 0 automatic, 1 pixels, 2 samples
     bool counters_enabled = false;
     unsigned long long last_trips = 0, last_phase2 = 0; // diagnostics of the counting kernel variant
@@ -200,13 +204,17 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
     const size_t lds_need = std::max(scene_lds_bytes(v), trt::persistent_lds_bytes(v, 64));
     if (lds_need > (size_t)ctx->lds_limit)
         return fail(TRT_ERR_CAPACITY, "scene needs %zu B of LDS staging, device offers %d", lds_need, ctx->lds_limit);
-    int blocks = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false, false>, trt::kPersistentBlock,
-                                                         trt::persistent_lds_bytes(v, 64)));
-    ctx->persistent_blocks_per_cu = std::max(blocks, 1);
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock,
-                                                         trt::persistent_lds_bytes(v, 64)));
-    ctx->rounds_blocks_per_cu = std::max(blocks, 1);
+    if (ctx->occupancy_for_lds != trt::persistent_lds_bytes(v, 64))
+    { // occupancy depends on the scene only through the LDS image size: query once per size, not once per frame
+        int blocks = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false, false>, trt::kPersistentBlock,
+                                                             trt::persistent_lds_bytes(v, 64)));
+        ctx->persistent_blocks_per_cu = std::max(blocks, 1);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock,
+                                                             trt::persistent_lds_bytes(v, 64)));
+        ctx->rounds_blocks_per_cu = std::max(blocks, 1);
+        ctx->occupancy_for_lds = trt::persistent_lds_bytes(v, 64);
+    }
     return TRT_OK;
 }
 
@@ -305,6 +313,8 @@ extern "C" int trt_create(int device, trt_context **out)
         HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
         HIP_TRY(hipEventCreate(&ctx->ev_stop[i]));
     }
+    for (int i = 0; i < 16; i++)
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
     HIP_TRY(ctx->d_counters.reserve(12));
     HIP_TRY(ctx->d_queue.reserve(64));
     HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, 12 * sizeof(unsigned long long)));
@@ -333,6 +343,8 @@ extern "C" int trt_destroy(trt_context *ctx)
         (void)hipEventDestroy(ctx->ev_start[i]);
         (void)hipEventDestroy(ctx->ev_stop[i]);
     }
+    for (int i = 0; i < 16; i++)
+        (void)hipEventDestroy(ctx->ev_chunk[i]);
     ctx->d_spheres.release();
     ctx->d_dir.release();
     ctx->d_point.release();
@@ -578,6 +590,19 @@ extern "C" int trt_synchronize(trt_context *ctx)
     return TRT_OK;
 }
 
+namespace
+{
+double host_now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+bool print_host_times()
+{
+    static const bool on = getenv("TRT_PRINT_HOST_TIMES") != nullptr;
+    return on;
+}
+} // namespace
+
 extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit,
                                int rays_per_pixel, Vector *pixels)
 {
@@ -598,12 +623,58 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
         HIP_TRY(hipHostMalloc((void **)&ctx->h_staging, std::max<size_t>(bytes, 1), hipHostMallocDefault));
         ctx->h_staging_bytes = std::max<size_t>(bytes, 1);
     }
+    const double t_begin = host_now_ms();
     int rc = trt_render_device(ctx, camera, rows, bounce_limit, rays_per_pixel, ctx->d_fb.ptr, bytes);
     if (rc)
         return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->h_staging, ctx->d_fb.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    const double t_enqueued = host_now_ms();
+    if (print_host_times())
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const double t_rendered = host_now_ms();
+    // Device -> pinned staging -> the caller's (pageable) buffer, pipelined: the frame goes over PCIe in chunks, an event
+    // marks each chunk, and a few host threads copy chunks out of the staging buffer as they land.
+    const int chunks = (int)std::min<size_t>(16, std::max<size_t>(1, bytes / (4u << 20)));
+    const size_t per = ((bytes + chunks - 1) / chunks + 63) / 64 * 64;
+    for (int i = 0; i < chunks; i++)
+    {
+        const size_t at = (size_t)i * per, len = at < bytes ? std::min(per, bytes - at) : 0;
+        if (len)
+            HIP_TRY(hipMemcpyAsync((char *)ctx->h_staging + at, (const char *)ctx->d_fb.ptr + at, len, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev_chunk[i], ctx->stream));
+    }
+    const int workers = chunks >= 4 ? 4 : 1;
+    hipError_t worker_error[4] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess};
+    auto drain = [&](int w) {
+        (void)hipSetDevice(ctx->device);
+        for (int i = w; i < chunks; i += workers)
+        {
+            const hipError_t e = hipEventSynchronize(ctx->ev_chunk[i]);
+            if (e != hipSuccess)
+            {
+                worker_error[w] = e;
+                return;
+            }
+            const size_t at = (size_t)i * per, len = at < bytes ? std::min(per, bytes - at) : 0;
+            memcpy((char *)pixels + at, (const char *)ctx->h_staging + at, len);
+        }
+    };
+    if (workers == 1)
+        drain(0);
+    else
+    {
+        std::thread pool[3];
+        for (int w = 1; w < workers; w++)
+            pool[w - 1] = std::thread(drain, w);
+        drain(0);
+        for (int w = 1; w < workers; w++)
+            pool[w - 1].join();
+    }
+    for (int w = 0; w < workers; w++)
+        HIP_TRY(worker_error[w]);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    memcpy(pixels, ctx->h_staging, bytes);
+    if (print_host_times())
+        fprintf(stderr, "trt_render_host: enqueue %.3f ms, kernels %.3f ms, copy-out of %zu bytes %.3f ms\n", t_enqueued - t_begin,
+                t_rendered - t_enqueued, bytes, host_now_ms() - t_rendered);
     return TRT_OK;
 }
 
@@ -779,6 +850,7 @@ extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_l
     if (rc)
         return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    const double t_begin = host_now_ms();
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     // the caller owns the scene and may have edited it since the last frame (main() rewrites the camera
     // every frame, TRT.c:1327-1336): primitives are a few KB and are re-sent; the 6*dim*dim texels only
@@ -797,6 +869,8 @@ extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_l
             return rc;
     }
     ctx->have_scene = true;
+    if (print_host_times())
+        fprintf(stderr, "trt_render_frame: scene upload %.3f ms\n", host_now_ms() - t_begin);
     const trt_rowset whole = {screen->width, screen->height, screen->height, 0, 1};
     return trt_render_host(ctx, &scene->camera, &whole, bounce_limit, rays_per_pixel, screen->pixels);
 }
