@@ -130,6 +130,13 @@ int trt_set_kernel(trt_context *ctx, int which);
  * frame (or a GPU's shard of it) has few pixels per resident lane; results are bit-identical either way. */
 int trt_set_work_units(trt_context *ctx, int units);
 
+/* Light-space candidate masks of the production kernel (csrc/trt_lightgrid.h): a shadow ray reads the spheres it can
+ * touch from a table of its light -- a directional_cells^2 grid across a directional light's direction, a cube map
+ * of 6 * point_cells^2 direction cells about a point light -- instead of sweeping all spheres.  Built on the host
+ * whenever the spheres or the lights change.  0, 0 turns the tables off (every shadow ray sweeps); results are
+ * bit-identical either way.  Defaults: 128 and 64; environment TRT_LIGHTGRID="d,p" overrides the defaults. */
+int trt_set_light_grids(trt_context *ctx, int directional_cells, int point_cells);
+
 /* Resource usage of the selected render kernel (hipFuncGetAttributes / occupancy query). */
 int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *static_lds_bytes, int *max_blocks_per_cu,
                     int *compute_units);

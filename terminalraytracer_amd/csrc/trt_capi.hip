@@ -15,6 +15,14 @@
 #include <thread>
 #include <vector>
 
+// light-space candidate masks: cells per side of a directional light's grid / of a point light's cube-map face
+#ifndef TRT_DIRGRID_CELLS
+#define TRT_DIRGRID_CELLS 128
+#endif
+#ifndef TRT_POINTGRID_CELLS
+#define TRT_POINTGRID_CELLS 64
+#endif
+
 #include "trt_device.hpp"
 #include "trt_persistent.hpp"
 #include "trt_rounds.hpp"
@@ -95,6 +103,14 @@ struct trt_context
     int persistent_blocks_per_cu = 0; // occupancy of the production kernel for the current scene's LDS image
     DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb, d_axes, d_samples;
     DeviceBuffer<float> d_cull;
+    // light-space candidate masks (trt_lightgrid.h) and the host copy of the primitives they were built from
+    DeviceBuffer<unsigned long long> d_dir_masks, d_point_masks;
+    DeviceBuffer<trt_dirgrid> d_dirgrids;
+    DeviceBuffer<trt_pointgrid> d_pointgrids;
+    trt::GridView grids{};
+    int dirgrid_cells = TRT_DIRGRID_CELLS, pointgrid_cells = TRT_POINTGRID_CELLS; // per side; 0 = no tables (sweep only)
+    std::vector<double> h_spheres, h_dir, h_point; // what the tables on the device were built from
+    int grids_built_for[2] = {-1, -1};
     DeviceBuffer<uint32_t> d_sky;
     DeviceBuffer<unsigned long long> d_counters;
     DeviceBuffer<unsigned int> d_queue;
@@ -159,6 +175,57 @@ int upload_skybox(trt_context *ctx, const Skybox *sky)
     return TRT_OK;
 }
 
+// Light-space candidate masks of every light, from the context's host copy of the primitives.
+int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
+{
+    const int n = (int)(ctx->h_spheres.size() / 9), nd = (int)(ctx->h_dir.size() / 6), np = (int)(ctx->h_point.size() / 7);
+    const int gd = ctx->dirgrid_cells, gp = ctx->pointgrid_cells;
+    trt::GridView &g = ctx->grids;
+    g = trt::GridView{};
+    ctx->grids_built_for[0] = gd;
+    ctx->grids_built_for[1] = gp;
+    if (gd < 8 || gp < 2 || nd + np == 0)
+        return TRT_OK; // enabled = 0: the kernel sweeps
+    const size_t words = (size_t)std::max((n + 63) / 64, 1);
+    const size_t dir_stride = (size_t)gd * gd * words, point_stride = 6 * (size_t)gp * gp * words;
+    std::vector<unsigned long long> dm(dir_stride * nd), pm(point_stride * np);
+    std::vector<trt_dirgrid> dg(nd);
+    std::vector<trt_pointgrid> pg(np);
+    for (int i = 0; i < nd; i++)
+    {
+        const double *li = ctx->h_dir.data() + 6 * i;
+        const double to_light[3] = {-li[0], -li[1], -li[2]}; // TRT.c:903; the builder normalises
+        const double len2 = to_light[0] * to_light[0] + to_light[1] * to_light[1] + to_light[2] * to_light[2];
+        if (!(len2 > 0.0) || !(len2 < 1e300))
+            return TRT_OK; // a light without a direction: leave the tables off
+        trt_dirgrid_build(ctx->h_spheres.data(), n, &cs, to_light, gd, &dg[i], dm.data() + dir_stride * i);
+    }
+    for (int i = 0; i < np; i++)
+        trt_pointgrid_build(ctx->h_spheres.data(), n, &cs, ctx->h_point.data() + 7 * i, gp, &pg[i], pm.data() + point_stride * i);
+    HIP_TRY(ctx->d_dir_masks.reserve(dm.size()));
+    HIP_TRY(ctx->d_point_masks.reserve(pm.size()));
+    HIP_TRY(ctx->d_dirgrids.reserve(nd));
+    HIP_TRY(ctx->d_pointgrids.reserve(np));
+    if (nd)
+    {
+        HIP_TRY(hipMemcpy(ctx->d_dir_masks.ptr, dm.data(), dm.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_dirgrids.ptr, dg.data(), dg.size() * sizeof(trt_dirgrid), hipMemcpyHostToDevice));
+    }
+    if (np)
+    {
+        HIP_TRY(hipMemcpy(ctx->d_point_masks.ptr, pm.data(), pm.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_pointgrids.ptr, pg.data(), pg.size() * sizeof(trt_pointgrid), hipMemcpyHostToDevice));
+    }
+    g.dir = ctx->d_dirgrids.ptr;
+    g.point = ctx->d_pointgrids.ptr;
+    g.dir_masks = ctx->d_dir_masks.ptr;
+    g.point_masks = ctx->d_point_masks.ptr;
+    g.dir_stride = (unsigned)dir_stride;
+    g.point_stride = (unsigned)point_stride;
+    g.enabled = 1;
+    return TRT_OK;
+}
+
 // everything of the scene except camera and skybox
 int upload_primitives(trt_context *ctx, const Scene *scene)
 {
@@ -192,6 +259,26 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
     ctx->cull.c0z = cs.c0[2];
     ctx->cull.cn = cs.cn;
     ctx->cull.rm = cs.rm;
+
+    // the light-space tables only change with the spheres and the lights (a render loop usually moves the camera only)
+    const double *hs = (const double *)scene->spheres, *hd = (const double *)scene->directional_lights, *hp = (const double *)scene->point_lights;
+    const bool same = ctx->h_spheres.size() == (size_t)n * 9 && ctx->h_dir.size() == (size_t)nd * 6 && ctx->h_point.size() == (size_t)np * 7 &&
+                      (!n || !memcmp(ctx->h_spheres.data(), hs, (size_t)n * sizeof(Sphere))) &&
+                      (!nd || !memcmp(ctx->h_dir.data(), hd, (size_t)nd * sizeof(DirectionalLight))) &&
+                      (!np || !memcmp(ctx->h_point.data(), hp, (size_t)np * sizeof(PointLight))) &&
+                      ctx->grids_built_for[0] == ctx->dirgrid_cells && ctx->grids_built_for[1] == ctx->pointgrid_cells;
+    if (!same)
+    {
+        ctx->h_spheres.assign(hs, hs + (size_t)n * 9);
+        ctx->h_dir.assign(hd, hd + (size_t)nd * 6);
+        ctx->h_point.assign(hp, hp + (size_t)np * 7);
+        const int rc = build_light_grids(ctx, cs);
+        if (rc)
+        {
+            ctx->grids_built_for[0] = ctx->grids_built_for[1] = -1;
+            return rc;
+        }
+    }
 
     trt::SceneView &v = ctx->scene;
     v.spheres = ctx->d_spheres.ptr;
@@ -306,6 +393,12 @@ extern "C" int trt_create(int device, trt_context **out)
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     ctx->compute_units = prop.multiProcessorCount;
     ctx->lds_limit = (int)prop.sharedMemPerBlock;
+    if (const char *e = getenv("TRT_LIGHTGRID"))
+    {
+        int gd = 0, gp = 0;
+        if (sscanf(e, "%d,%d", &gd, &gp) == 2 && gd >= 0 && gp >= 0 && gd <= 2048 && gp <= 1024)
+            ctx->dirgrid_cells = gd, ctx->pointgrid_cells = gp;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < kEventRing; i++)
@@ -353,6 +446,10 @@ extern "C" int trt_destroy(trt_context *ctx)
     ctx->d_samples.release();
     ctx->d_fb.release();
     ctx->d_cull.release();
+    ctx->d_dir_masks.release();
+    ctx->d_point_masks.release();
+    ctx->d_dirgrids.release();
+    ctx->d_pointgrids.release();
     ctx->d_sky.release();
     ctx->d_counters.release();
     ctx->d_queue.release();
@@ -416,6 +513,23 @@ extern "C" int trt_set_work_units(trt_context *ctx, int units)
         return fail(TRT_ERR_ARGUMENT, "units %d", units);
     ctx->units = units;
     return TRT_OK;
+}
+
+extern "C" int trt_set_light_grids(trt_context *ctx, int directional_cells, int point_cells)
+{
+    if (!ctx || directional_cells < 0 || point_cells < 0 || directional_cells > 2048 || point_cells > 1024)
+        return fail(TRT_ERR_ARGUMENT, "light grids %d, %d", directional_cells, point_cells);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still read the old tables
+    ctx->dirgrid_cells = directional_cells;
+    ctx->pointgrid_cells = point_cells;
+    if (!ctx->have_scene)
+        return TRT_OK;
+    const int n = (int)(ctx->h_spheres.size() / 9);
+    std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
+    trt_cull_scene cs;
+    trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
+    return build_light_grids(ctx, cs);
 }
 
 extern "C" int trt_enable_counters(trt_context *ctx, int enable)
@@ -539,9 +653,9 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
         if (rounds)
         {
             if (count)
-                hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+                hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f, ctx->grids);
             else
-                hipLaunchKernelGGL((trt::render_rounds_kernel<false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+                hipLaunchKernelGGL((trt::render_rounds_kernel<false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f, ctx->grids);
         }
         else if (sample_units)
         {

@@ -31,6 +31,7 @@
 
 #include "trt_device.hpp"
 #include "trt_filter.h"
+#include "trt_lightgrid.h"
 #include "trt_persistent.hpp"
 
 namespace trt
@@ -45,6 +46,16 @@ namespace trt
 #ifndef TRT_SWEEP_MFMA
 #define TRT_SWEEP_MFMA 0
 #endif
+
+// Light-space candidate masks (trt_lightgrid.h): per light one table of cells, each cell `words` 64-bit masks.
+struct GridView
+{
+    const trt_dirgrid *dir;     // [num_dir]
+    const trt_pointgrid *point; // [num_point]
+    const unsigned long long *dir_masks, *point_masks;
+    unsigned dir_stride, point_stride; // words per light
+    int enabled;
+};
 
 struct LdsImage
 {
@@ -226,9 +237,12 @@ TRT_DEV void sweep64_mfma(const float *a_xy, const float *a_zk, int lane, const 
 // Closest hit of TRT.c:793-856 for the lanes with `active`.  ANY_HIT: the caller only asks whether anything
 // is hit (directional-light shadow ray, TRT.c:908), so a lane stops at its first hit and the ground is skipped
 // once a sphere was found.  `a_zk_fixed` != nullptr: all rays share the direction that table was built for.
+// `use_masks` (wave-uniform): the candidates come from this lane's cell of a light-space table (`masks`, one word per
+// chunk of 64 spheres) instead of the sweep.
 template <bool ANY_HIT>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
-                  int lane, const float4 *fixed = nullptr, const float *a_zk_fixed = nullptr)
+                  int lane, const float4 *fixed = nullptr, const float *a_zk_fixed = nullptr, bool use_masks = false,
+                  const unsigned long long *masks = nullptr)
 {
     (void)lane;
     (void)fixed;
@@ -239,7 +253,8 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     best.i = -1;
     const double a = dot(d, d);
     trt_ray_filter flt;
-    trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
+    if (TRT_SWEEP_MFMA || !use_masks)
+        trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
 
 #if TRT_SWEEP_MFMA
     for (int base = 0; base < L.padded64; base += 64)
@@ -299,6 +314,11 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         // phase 1: wave-uniform sweep; each verdict is a sign bit shifted into a per-lane word by v_alignbit,
         // sphere base+j ends up at bit 63-j of `cand`
         const int chunk = (cull.padded - base) < 64 ? (cull.padded - base) : 64;
+        unsigned long long cand;
+        if (use_masks)
+            cand = active ? masks[base >> 6] : 0ull;
+        else
+        {
         unsigned word[2];
 #pragma unroll
         for (int h = 0; h < 2; h++)
@@ -324,11 +344,12 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
             }
             word[h] = count > 0 ? ~(bits << (32 - count)) & (count == 32 ? ~0u : ~((1u << (32 - count)) - 1u)) : 0u;
         }
-        unsigned long long cand = ((unsigned long long)word[0] << 32) | word[1];
+        cand = ((unsigned long long)word[0] << 32) | word[1];
         if (!flt.ok)
             cand = chunk == 64 ? ~0ull : ~((1ull << (64 - chunk)) - 1ull); // degenerate ray: every sphere of the chunk
         if (!active)
             cand = 0;
+        }
         // phase 2: exact FP64 tests of this lane's candidates, ascending index (first index wins ties, TRT.c:816)
         while (__any(cand != 0))
         {
@@ -404,7 +425,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
 #endif
 
 template <bool COUNT>
-__global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f)
+__global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const LdsImage L = stage_lds_image(lds, s, cull, f);
@@ -552,8 +573,20 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                 { // directional light, TRT.c:900-923
                     sd = load3(L.dir + li * 6);
                     lcolor = load3(L.dir + li * 6 + 3);
+                    // candidates from the light's table unless some lane's origin is outside its range (trt_lightgrid.h)
+                    bool use_masks = false;
+                    const unsigned long long *cell = nullptr;
+                    if (grids.enabled)
+                    {
+                        const trt_dirgrid *G = grids.dir + li;
+                        int far;
+                        const int c = trt_dirgrid_cell(G, o.x, o.y, o.z, &far);
+                        far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
+                        use_masks = !__any(path_hit && far);
+                        cell = grids.dir_masks + (size_t)li * grids.dir_stride + (unsigned)c * (unsigned)G->words;
+                    }
                     const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, L.cull_dir + li * cull.padded,
-                                               L.a_zk_dir + li * 2 * L.padded64);
+                                               L.a_zk_dir + li * 2 * L.padded64, use_masks, cell);
                     is_lit = sh.i < 0;
                     factor = min1(dot(h_normal, sd));
                     TRT_STAMP_AT(4); // directional shadow
@@ -566,7 +599,18 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                     const double strength = clampd(pl[6] / light_d2, 0.0, 1.0);
                     sd = unit(to_light);
                     lcolor = load3(pl + 3);
-                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane);
+                    bool use_masks = false;
+                    const unsigned long long *cell = nullptr;
+                    if (grids.enabled)
+                    {
+                        const trt_pointgrid *G = grids.point + (li - nd);
+                        int far;
+                        const int c = trt_pointgrid_cell(G, o.x, o.y, o.z, &far);
+                        far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
+                        use_masks = !__any(path_hit && far);
+                        cell = grids.point_masks + (size_t)(li - nd) * grids.point_stride + (unsigned)c * (unsigned)G->words;
+                    }
+                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, nullptr, nullptr, use_masks, cell);
                     is_lit = sh.i < 0;
                     // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the
                     // blocker point NUDGED 1e-6 back along the ray (TRT.c:871-874, :939-942): (D - 1e-6)^2 up to ~1e-14 relative

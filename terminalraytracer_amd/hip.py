@@ -67,6 +67,7 @@ SYMBOLS = {
     "trt_read_diagnostics": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "trt_set_kernel": (_I, [_VP, _I]),
     "trt_set_work_units": (_I, [_VP, _I]),
+    "trt_set_light_grids": (_I, [_VP, _I, _I]),
     "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
     "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
     "trt_probe_rays": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
@@ -147,6 +148,10 @@ class Context:
     def set_work_units(self, units):
         """0 automatic, 1 pixels, 2 samples (trt_set_work_units)"""
         _check(lib().trt_set_work_units(self._h, units))
+
+    def set_light_grids(self, directional_cells, point_cells):
+        """cells per side of the light-space candidate tables; 0, 0 = off (trt_set_light_grids)"""
+        _check(lib().trt_set_light_grids(self._h, directional_cells, point_cells))
 
     def render_device(self, camera_array, rows, bounce_limit, rays_per_pixel, device_ptr, capacity_bytes):
         cam = camera_struct(camera_array)

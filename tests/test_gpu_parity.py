@@ -389,3 +389,27 @@ def test_rgb8_sharded_renderer_feeds_the_emitter(ctx):
     em = host.Emitter(160, 48)
     em.patch_rgb8(rgb)
     assert em.bytes() == zlib.decompress(open(T.GOLDEN + "/emit_demo_160x48_b4.bin.z", "rb").read())
+
+
+@pytest.mark.parametrize("cells", [(0, 0), (8, 2), (33, 7), (512, 256)], ids=["off", "coarsest", "odd", "fine"])
+def test_light_space_tables_never_change_a_frame(ctx, cells):
+    """The production kernel reads a shadow ray's candidate spheres from per-light tables (csrc/trt_lightgrid.h).  Whatever
+    their resolution -- or with the tables off, every shadow ray sweeping -- frames must equal the oracle bit for bit:
+    64 and 256 spheres (one and four mask words per cell), lights inside / on / a hair outside spheres, many lights."""
+    cases = [(S.synth_scene(64, T.sky("synth"), T.bench_camera(96, 54)), 96, 54, 8, 10),
+             (S.synth_scene(256, T.sky("synth"), T.bench_camera(64, 36, 2.5)), 64, 36, 6, 4)]
+    base = S.synth_scene(40, T.sky("synth"), T.bench_camera(80, 45, 10.0), seed=5)
+    c, r = base.spheres[3, :3], base.spheres[3, 3]
+    lights = [list(c) + [1.0, 1.0, 1.0, 5.0], list(c + [0.0, r * 0.999, 0.0]) + [0.2, 1.0, 0.3, 9.0],
+              list(c + [r * (1 + 1e-9), 0.0, 0.0]) + [1.0, 0.3, 0.2, 9.0], list(c + [0.0, 0.0, r + 0.03]) + [0.5, 0.5, 1.0, 20.0],
+              [0.0, 300.0, 0.0, 1.0, 1.0, 1.0, 9e4]]
+    dirs = np.array([[0.0, -1.0, 0.0, 0.5, 0.5, 0.5], [1.0, -1e-9, 0.0, 0.3, 0.2, 0.1], [-0.3, -0.8, 0.55, 0.2, 0.3, 0.4]])
+    cases.append((S.SceneData(base.spheres, base.ground, dirs, np.array(lights), base.camera, base.sky), 80, 45, 5, 5))
+    try:
+        for scene, w, h, b, spp in cases:
+            want, _ = T.oracle_render(scene, w, h, b, spp)
+            ctx.set_light_grids(*cells)
+            got = render(ctx, scene, w, h, b, spp)
+            assert np.array_equal(bits(got), bits(want)), (cells, len(scene.spheres))
+    finally:
+        ctx.set_light_grids(128, 64)
