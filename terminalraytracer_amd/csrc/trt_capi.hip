@@ -50,6 +50,7 @@ int fail(int code, const char *fmt, ...)
             return fail(TRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+constexpr int kCounterSlots = 32; // [path, shadow, rounds, phase-2 rounds, 24 stage stamps of the diagnostic build]
 constexpr int kEventRing = 256;
 constexpr double kPi = 3.14159265358979323846; // TRT.c:43
 
@@ -408,9 +409,9 @@ extern "C" int trt_create(int device, trt_context **out)
     }
     for (int i = 0; i < 16; i++)
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
-    HIP_TRY(ctx->d_counters.reserve(12));
+    HIP_TRY(ctx->d_counters.reserve(kCounterSlots));
     HIP_TRY(ctx->d_queue.reserve(64));
-    HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, 12 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int)));
     // dynamic LDS above the 64 KiB default needs the opt-in attribute
     (void)hipFuncSetAttribute((const void *)trt::render_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
@@ -546,20 +547,25 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long c[12];
+    unsigned long long c[kCounterSlots];
     HIP_TRY(hipMemcpy(c, ctx->d_counters.ptr, sizeof c, hipMemcpyDeviceToHost));
     ctx->last_trips = c[2];
     ctx->last_phase2 = c[3];
     if (getenv("TRT_PRINT_STAMPS"))
     { // diagnostic builds only (-DTRT_STAMP=1): per-stage wave-cycle sums
         static const char *const names_sm[8] = {"filter set-up", "phase 1 sweep", "phase 2 exact", "plane", "POST", "NORM", "FINISH", "loop edge"};
-        static const char *const names_rounds[8] = {"units+primary", "unit(next_dir)", "P trace", "P post", "S directional", "S point", "lit accumulate", "END+edge"};
-        const char *const *names = ctx->kernel == 0 && ctx->units != 1 ? names_rounds : names_sm;
+        static const char *const names_rounds[24] = {"units+primary", "unit(next_dir)", "P set-up", "P sweep", "P exact tests", "P plane",
+                                                     "P post: hit", "P post: sky", "Sd look-up", "Sd set-up/load", "Sd sweep", "Sd exact tests",
+                                                     "Sd plane", "Sd tail", "Sp unit/look-up", "Sp set-up/load", "Sp sweep", "Sp exact tests",
+                                                     "Sp plane", "Sp tail", "lit accumulate", "END", "loop edge", "-"};
+        const bool rounds = ctx->kernel == 0 && ctx->units != 1;
+        const char *const *names = rounds ? names_rounds : names_sm;
+        const int slots = rounds ? 24 : 8;
         unsigned long long total = 0;
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < slots; i++)
             total += c[4 + i];
-        for (int i = 0; i < 8 && total; i++)
-            fprintf(stderr, "stamp %-14s %6.2f %%  %llu\n", names[i], 100.0 * c[4 + i] / total, c[4 + i]);
+        for (int i = 0; i < slots && total; i++)
+            fprintf(stderr, "stamp %-16s %6.2f %%  %llu\n", names[i], 100.0 * c[4 + i] / total, c[4 + i]);
     }
     if (path_rays)
         *path_rays = c[0];
@@ -617,7 +623,7 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
     const long pixels = (long)local_rows * rows->width;
     const size_t lds = scene_lds_bytes(ctx->scene);
     if (ctx->counters_enabled)
-        HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, 12 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long), ctx->stream));
     const int slot = (int)(ctx->launches % kEventRing);
     if (ctx->kernel == 1)
     {

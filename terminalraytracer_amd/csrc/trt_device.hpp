@@ -132,7 +132,12 @@ TRT_DEV bool hit_plane(d3 o, d3 d, d3 gp, d3 gn, d3 &p)
     double denom = dot(d, gn);
     if (!(__builtin_fabs(denom) > 0.00001))
         return false;
-    double t = dot(sub(gp, o), gn) / denom;
+    const double num = dot(sub(gp, o), gn);
+    // numerator and denominator of opposite sign: t <= 0 (or -0), a miss whatever the quotient's digits are.  Decided
+    // from the sign bits so that a wave whose rays all head away from the plane skips the division (NaN passes on).
+    if ((long long)(__builtin_bit_cast(unsigned long long, num) ^ __builtin_bit_cast(unsigned long long, denom)) < 0)
+        return false;
+    double t = num / denom;
     if (!(t > 0.00001))
         return false;
     p = d3{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};

@@ -242,8 +242,22 @@ TRT_DEV void sweep64_mfma(const float *a_xy, const float *a_zk, int lane, const 
 template <bool ANY_HIT>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
                   int lane, const float4 *fixed = nullptr, const float *a_zk_fixed = nullptr, bool use_masks = false,
-                  const unsigned long long *masks = nullptr)
+                  const unsigned long long *masks = nullptr
+#if TRT_STAMP
+                  ,
+                  unsigned long long *stamp_sum = nullptr, unsigned long long *stamp_prev_p = nullptr, int stamp_base = 0
+#endif
+)
 {
+#if TRT_STAMP
+    unsigned long long &stamp_prev = *stamp_prev_p;
+#define TRT_TRACE_STAMP(k) TRT_STAMP_AT(stamp_base + (k))
+#else
+#define TRT_TRACE_STAMP(k) \
+    do                     \
+    {                      \
+    } while (0)
+#endif
     (void)lane;
     (void)fixed;
     (void)a_zk_fixed;
@@ -316,9 +330,16 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         const int chunk = (cull.padded - base) < 64 ? (cull.padded - base) : 64;
         unsigned long long cand;
         if (use_masks)
+        {
             cand = active ? masks[base >> 6] : 0ull;
+#if TRT_STAMP
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            TRT_TRACE_STAMP(0); // set-up / table load
+        }
         else
         {
+        TRT_TRACE_STAMP(0);
         unsigned word[2];
 #pragma unroll
         for (int h = 0; h < 2; h++)
@@ -349,6 +370,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
             cand = chunk == 64 ? ~0ull : ~((1ull << (64 - chunk)) - 1ull); // degenerate ray: every sphere of the chunk
         if (!active)
             cand = 0;
+        TRT_TRACE_STAMP(1); // sweep
         }
         // phase 2: exact FP64 tests of this lane's candidates, ascending index (first index wins ties, TRT.c:816)
         while (__any(cand != 0))
@@ -394,6 +416,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         }
     }
 #endif
+    TRT_TRACE_STAMP(2); // exact tests
     // ground plane (TRT.c:831-853)
     if (active && !(ANY_HIT && best.i >= 0))
     {
@@ -414,6 +437,8 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
             }
         }
     }
+    TRT_TRACE_STAMP(3); // plane
+#undef TRT_TRACE_STAMP
     return best;
 }
 
@@ -448,12 +473,12 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
     unsigned pool_next = 0, pool_end = 0; // wave-uniform: units fetched from the queue, not yet handed out
 
 #if TRT_STAMP
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    unsigned long long stamp_sum[24] = {0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     for (;;)
     {
-        TRT_STAMP_AT(7); // END of bounce + loop edge
+        TRT_STAMP_AT(22); // loop edge
         // =============== hand out work units; primary rays of new samples (TRT.c:981-1016) ===============
         {
             const unsigned long long need = __ballot(want_unit);
@@ -524,8 +549,11 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
         if (COUNT && alive)
             n_path++;
         TRT_STAMP_AT(1); // unit(next_dir)
+#if TRT_STAMP
+        const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2, lane, nullptr, nullptr, false, nullptr, stamp_sum, &stamp_prev, 2);
+#else
         const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2, lane);
-        TRT_STAMP_AT(2); // P trace
+#endif
         const bool path_hit = alive && ph.i >= 0, path_sky = alive && ph.i < 0;
 
         // one unit() for "back along the ray" (nudge, TRT.c:871-872) or the sky direction (TRT.c:702), one for the normal
@@ -543,6 +571,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             }
             h_normal = unit(raw); // TRT.c:878
         }
+        TRT_STAMP_AT(6); // P post: nudge direction, normal
         bool end_sample = false;
         double weight_sum_new = weight_sum + weight; // TRT.c:1034
         if (path_sky)
@@ -558,7 +587,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             o = add(ph.p, scale(nA, 0.000001));     // TRT.c:873-874; origin of the shadow rays and of the next path ray
         }
 
-        TRT_STAMP_AT(3); // P post: nudge/normal/sky
+        TRT_STAMP_AT(7); // P post: sky texel, reflection, nudge
         // ======================================= S(i): shadow rays =======================================
         if (__any(path_hit))
         {
@@ -585,11 +614,17 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                         use_masks = !__any(path_hit && far);
                         cell = grids.dir_masks + (size_t)li * grids.dir_stride + (unsigned)c * (unsigned)G->words;
                     }
+                    TRT_STAMP_AT(8); // look-up
+#if TRT_STAMP
+                    const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, L.cull_dir + li * cull.padded,
+                                               L.a_zk_dir + li * 2 * L.padded64, use_masks, cell, stamp_sum, &stamp_prev, 9);
+#else
                     const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, L.cull_dir + li * cull.padded,
                                                L.a_zk_dir + li * 2 * L.padded64, use_masks, cell);
+#endif
                     is_lit = sh.i < 0;
                     factor = min1(dot(h_normal, sd));
-                    TRT_STAMP_AT(4); // directional shadow
+                    TRT_STAMP_AT(13); // directional shadow tail
                 }
                 else
                 { // point light, TRT.c:926-957
@@ -610,7 +645,12 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                         use_masks = !__any(path_hit && far);
                         cell = grids.point_masks + (size_t)(li - nd) * grids.point_stride + (unsigned)c * (unsigned)G->words;
                     }
+                    TRT_STAMP_AT(14); // unit(to_light), strength, look-up
+#if TRT_STAMP
+                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, nullptr, nullptr, use_masks, cell, stamp_sum, &stamp_prev, 15);
+#else
                     const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, nullptr, nullptr, use_masks, cell);
+#endif
                     is_lit = sh.i < 0;
                     // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the
                     // blocker point NUDGED 1e-6 back along the ray (TRT.c:871-874, :939-942): (D - 1e-6)^2 up to ~1e-14 relative
@@ -629,14 +669,14 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                             is_lit = light_d2 < dot(to_blocker, to_blocker);
                     }
                     factor = strength * min1(dot(h_normal, sd));
-                    TRT_STAMP_AT(5); // point shadow
+                    TRT_STAMP_AT(19); // point shadow tail
                 }
                 if (path_hit && is_lit)
                     lit = add(lit, mulc(scale(lcolor, factor), load3(L.mat + h_mat * 5)));
             }
         }
 
-        TRT_STAMP_AT(6); // lit accumulate
+        TRT_STAMP_AT(20); // lit accumulate
         // ======================================= END of the bounce =======================================
         if (path_hit)
         { // TRT.c:960-962 then :1034-1048
@@ -662,6 +702,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                 want_unit = true;
             }
         }
+        TRT_STAMP_AT(21); // END of the bounce
     }
 
     if (COUNT && f.counters)
@@ -673,7 +714,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             atomicAdd(&f.counters[2], (unsigned long long)n_rounds);
             atomicAdd(&f.counters[3], (unsigned long long)n_phase2);
 #if TRT_STAMP
-            for (int i = 0; i < 8; i++)
+            for (int i = 0; i < 24; i++)
                 atomicAdd(&f.counters[4 + i], stamp_sum[i]);
 #endif
         }
