@@ -137,6 +137,11 @@ int trt_set_work_units(trt_context *ctx, int units);
  * bit-identical either way.  Defaults: 128 and 64; environment TRT_LIGHTGRID="d,p" overrides the defaults. */
 int trt_set_light_grids(trt_context *ctx, int directional_cells, int point_cells);
 
+/* Copy one light's table to the host (tests: the device-built table must equal the host reference builder's).
+ * point_light: 0 = directional light `index`, 1 = point light `index`.  Returns the number of 64-bit words copied
+ * (cells * ceil(N/64)), 0 when the tables are off, or a negative TRT_ERR_*. */
+long trt_read_light_grid(trt_context *ctx, int point_light, int index, unsigned long long *masks, size_t capacity_words);
+
 /* Resource usage of the selected render kernel (hipFuncGetAttributes / occupancy query). */
 int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *static_lds_bytes, int *max_blocks_per_cu,
                     int *compute_units);

@@ -108,6 +108,8 @@ struct trt_context
     DeviceBuffer<unsigned long long> d_dir_masks, d_point_masks;
     DeviceBuffer<trt_dirgrid> d_dirgrids;
     DeviceBuffer<trt_pointgrid> d_pointgrids;
+    DeviceBuffer<trt_dirgrid_disc> d_discs;   // per directional light and sphere: what the marking kernel reads
+    DeviceBuffer<trt_pointgrid_cone> d_cones; // per point light and sphere
     trt::GridView grids{};
     int dirgrid_cells = TRT_DIRGRID_CELLS, pointgrid_cells = TRT_POINTGRID_CELLS; // per side; 0 = no tables (sweep only)
     std::vector<double> h_spheres, h_dir, h_point; // what the tables on the device were built from
@@ -176,7 +178,42 @@ int upload_skybox(trt_context *ctx, const Skybox *sky)
     return TRT_OK;
 }
 
-// Light-space candidate masks of every light, from the context's host copy of the primitives.
+// Marking kernels of the light-space tables: one thread per cell, every sphere tested with the predicates of
+// trt_lightgrid.h (+ - * / sqrt only: the host reference builders in the tests produce the same bits).
+__global__ void build_dirgrid_kernel(const trt_dirgrid_disc *discs, int n, int g, int words, unsigned long long *masks)
+{
+    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= (long)g * g)
+        return;
+    const int c = (int)(cell % g), j = (int)(cell / g);
+    for (int w = 0; w < words; w++)
+    {
+        unsigned long long m = 0;
+        for (int b = 0; b < 64 && w * 64 + b < n; b++)
+            if (trt_dirgrid_reaches(discs + w * 64 + b, c, j))
+                m |= 0x8000000000000000ull >> b;
+        masks[cell * words + w] = m;
+    }
+}
+
+__global__ void build_pointgrid_kernel(const trt_pointgrid_cone *cones, int n, int g, int words, unsigned long long *masks)
+{
+    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= 6L * g * g)
+        return;
+    const int face = (int)(cell / ((long)g * g)), j = (int)((cell / g) % g), c = (int)(cell % g);
+    for (int w = 0; w < words; w++)
+    {
+        unsigned long long m = 0;
+        for (int b = 0; b < 64 && w * 64 + b < n; b++)
+            if (trt_pointgrid_reaches(cones + w * 64 + b, face, c, j, g))
+                m |= 0x8000000000000000ull >> b;
+        masks[cell * words + w] = m;
+    }
+}
+
+// Light-space candidate masks of every light (trt_lightgrid.h), from the context's host copy of the primitives: the
+// host places each grid and prepares one small record per sphere and light, the device marks the cells.
 int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
 {
     const int n = (int)(ctx->h_spheres.size() / 9), nd = (int)(ctx->h_dir.size() / 6), np = (int)(ctx->h_point.size() / 7);
@@ -187,36 +224,48 @@ int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
     ctx->grids_built_for[1] = gp;
     if (gd < 8 || gp < 2 || nd + np == 0)
         return TRT_OK; // enabled = 0: the kernel sweeps
-    const size_t words = (size_t)std::max((n + 63) / 64, 1);
+    const size_t words = (size_t)std::max((n + 63) / 64, 1), slots = (size_t)std::max(n, 1);
     const size_t dir_stride = (size_t)gd * gd * words, point_stride = 6 * (size_t)gp * gp * words;
-    std::vector<unsigned long long> dm(dir_stride * nd), pm(point_stride * np);
     std::vector<trt_dirgrid> dg(nd);
     std::vector<trt_pointgrid> pg(np);
+    std::vector<trt_dirgrid_disc> discs(slots * nd);
+    std::vector<trt_pointgrid_cone> cones(slots * np);
     for (int i = 0; i < nd; i++)
     {
         const double *li = ctx->h_dir.data() + 6 * i;
-        const double to_light[3] = {-li[0], -li[1], -li[2]}; // TRT.c:903; the builder normalises
+        const double to_light[3] = {-li[0], -li[1], -li[2]}; // TRT.c:903; prepare normalises
         const double len2 = to_light[0] * to_light[0] + to_light[1] * to_light[1] + to_light[2] * to_light[2];
         if (!(len2 > 0.0) || !(len2 < 1e300))
             return TRT_OK; // a light without a direction: leave the tables off
-        trt_dirgrid_build(ctx->h_spheres.data(), n, &cs, to_light, gd, &dg[i], dm.data() + dir_stride * i);
+        trt_dirgrid_prepare(ctx->h_spheres.data(), n, &cs, to_light, gd, &dg[i], discs.data() + slots * i);
     }
     for (int i = 0; i < np; i++)
-        trt_pointgrid_build(ctx->h_spheres.data(), n, &cs, ctx->h_point.data() + 7 * i, gp, &pg[i], pm.data() + point_stride * i);
-    HIP_TRY(ctx->d_dir_masks.reserve(dm.size()));
-    HIP_TRY(ctx->d_point_masks.reserve(pm.size()));
+        trt_pointgrid_prepare(ctx->h_spheres.data(), n, &cs, ctx->h_point.data() + 7 * i, gp, &pg[i], cones.data() + slots * i);
+    HIP_TRY(ctx->d_dir_masks.reserve(dir_stride * nd));
+    HIP_TRY(ctx->d_point_masks.reserve(point_stride * np));
     HIP_TRY(ctx->d_dirgrids.reserve(nd));
     HIP_TRY(ctx->d_pointgrids.reserve(np));
+    HIP_TRY(ctx->d_discs.reserve(discs.size()));
+    HIP_TRY(ctx->d_cones.reserve(cones.size()));
     if (nd)
     {
-        HIP_TRY(hipMemcpy(ctx->d_dir_masks.ptr, dm.data(), dm.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->d_dirgrids.ptr, dg.data(), dg.size() * sizeof(trt_dirgrid), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_discs.ptr, discs.data(), discs.size() * sizeof(trt_dirgrid_disc), hipMemcpyHostToDevice));
     }
     if (np)
     {
-        HIP_TRY(hipMemcpy(ctx->d_point_masks.ptr, pm.data(), pm.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->d_pointgrids.ptr, pg.data(), pg.size() * sizeof(trt_pointgrid), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_cones.ptr, cones.data(), cones.size() * sizeof(trt_pointgrid_cone), hipMemcpyHostToDevice));
     }
+    const int block = 256;
+    for (int i = 0; i < nd; i++)
+        hipLaunchKernelGGL(build_dirgrid_kernel, dim3((unsigned)(((size_t)gd * gd + block - 1) / block)), dim3(block), 0, ctx->stream,
+                           ctx->d_discs.ptr + slots * i, n, gd, (int)words, ctx->d_dir_masks.ptr + dir_stride * i);
+    for (int i = 0; i < np; i++)
+        hipLaunchKernelGGL(build_pointgrid_kernel, dim3((unsigned)((6 * (size_t)gp * gp + block - 1) / block)), dim3(block), 0, ctx->stream,
+                           ctx->d_cones.ptr + slots * i, n, gp, (int)words, ctx->d_point_masks.ptr + point_stride * i);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // the caller may hand the context another stream before it renders
     g.dir = ctx->d_dirgrids.ptr;
     g.point = ctx->d_pointgrids.ptr;
     g.dir_masks = ctx->d_dir_masks.ptr;
@@ -451,6 +500,8 @@ extern "C" int trt_destroy(trt_context *ctx)
     ctx->d_point_masks.release();
     ctx->d_dirgrids.release();
     ctx->d_pointgrids.release();
+    ctx->d_discs.release();
+    ctx->d_cones.release();
     ctx->d_sky.release();
     ctx->d_counters.release();
     ctx->d_queue.release();
@@ -531,6 +582,27 @@ extern "C" int trt_set_light_grids(trt_context *ctx, int directional_cells, int 
     trt_cull_scene cs;
     trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
     return build_light_grids(ctx, cs);
+}
+
+extern "C" long trt_read_light_grid(trt_context *ctx, int point_light, int index, unsigned long long *masks, size_t capacity_words)
+{
+    if (!ctx || !masks || index < 0)
+        return fail(TRT_ERR_ARGUMENT, "bad argument");
+    if (!ctx->have_scene)
+        return fail(TRT_ERR_NO_SCENE, "no scene");
+    const trt::GridView &g = ctx->grids;
+    if (!g.enabled)
+        return 0;
+    if (index >= (point_light ? ctx->scene.num_point : ctx->scene.num_dir))
+        return fail(TRT_ERR_ARGUMENT, "light %d", index);
+    const size_t stride = point_light ? g.point_stride : g.dir_stride;
+    if (capacity_words < stride)
+        return fail(TRT_ERR_CAPACITY, "table has %zu words, buffer %zu", stride, capacity_words);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(masks, (point_light ? g.point_masks : g.dir_masks) + stride * (size_t)index, stride * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost));
+    return (long)stride;
 }
 
 extern "C" int trt_enable_counters(trt_context *ctx, int enable)

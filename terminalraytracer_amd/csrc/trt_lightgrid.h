@@ -116,14 +116,86 @@ TRT_HD int trt_pointgrid_cell(const trt_pointgrid *G, double ox, double oy, doub
     return (face * G->g + (int)cv) * G->g + (int)cu;
 }
 
-/* ------------------------------------------- builders (host) ------------------------------------------- */
-/* sphere j of a chunk of 64 sits at bit 63 - j, the order the exact stage walks with count-leading-zeros */
-static inline void trt_lightgrid_set(unsigned long long *cell, int sphere) { cell[sphere >> 6] |= 0x8000000000000000ull >> (sphere & 63); }
+/* ------------------------------------------------ builders ------------------------------------------------
+ * A table is built in two steps: a per-light PREPARE on the host (O(N): grid placement, one small record per
+ * sphere) and the marking of every (cell, sphere) pair by a predicate that uses only + - * / and sqrt -- IEEE
+ * operations that round identically on the host and on the device -- so the device kernels (trt_capi.hip, one
+ * thread per cell) and the host reference builders below (tests) produce the same tables bit for bit. */
 
-/* Directional light with unit to-light direction `to_light` (TRT.c:903-904).  `masks` must hold g*g*words words.
- * cs: the culling table's scene constants (shift and bounds).  Returns the number of (cell, sphere) bits set. */
-static inline long trt_dirgrid_build(const double *spheres, int n, const trt_cull_scene *cs, const double to_light[3], int g,
-                                     trt_dirgrid *G, unsigned long long *masks)
+/* sphere j of a chunk of 64 sits at bit 63 - j, the order the exact stage walks with count-leading-zeros */
+TRT_HD void trt_lightgrid_set(unsigned long long *cell, int sphere) { cell[sphere >> 6] |= 0x8000000000000000ull >> (sphere & 63); }
+
+/* a sphere as a directional light's grid sees it: disc centre and radius in CELL units, growth included */
+typedef struct
+{
+    double pu, pv, rad;
+} trt_dirgrid_disc;
+
+/* a sphere as a point light's cube map sees it: unit axis light -> centre, sine and cosine of the grown half-angle */
+typedef struct
+{
+    double a[3];
+    double sin_a, cos_a;
+    double everywhere; /* != 0: the light is inside or next to the sphere, every cell holds it */
+} trt_pointgrid_cone;
+
+/* does the disc reach cell (c, j), the cell grown by 0.01 on every side? */
+TRT_HD int trt_dirgrid_reaches(const trt_dirgrid_disc *s, int c, int j)
+{
+    const double x0 = (double)c - 0.01, x1 = (double)c + 1.01, y0 = (double)j - 0.01, y1 = (double)j + 1.01;
+    const double nx = s->pu < x0 ? x0 - s->pu : (s->pu > x1 ? s->pu - x1 : 0.0);
+    const double ny = s->pv < y0 ? y0 - s->pv : (s->pv > y1 ? s->pv - y1 : 0.0);
+    return nx * nx + ny * ny <= s->rad * s->rad;
+}
+
+/* tangent of (45 degrees + 1e-4 rad) and a little more: how far an edge cell stretches past the face's edge */
+#define TRT_POINTGRID_EDGE 1.00021
+
+/* One edge of a cell in the face frame (p, q, m): the directions (e, t, 1), t in [t0, t1] (p is the coordinate held
+ * fixed at e).  Does the cone come within its half-angle of that arc's INTERIOR?  (End points are the cell's corners,
+ * tested separately.)  The arc lies on the great circle with unit normal (1, 0, -e)/sqrt(1 + e^2); the angle between
+ * the axis and that circle has sine |h|, and the nearest point of the circle is the foot f of the axis in its plane. */
+TRT_HD int trt_cone_near_edge(double ap, double aq, double am, double sin_a, double e, double t0, double t1)
+{
+    const double nl = __builtin_sqrt(1.0 + e * e);
+    const double h = (ap - e * am) / nl;
+    if (!(__builtin_fabs(h) <= sin_a))
+        return 0;
+    const double fq = aq, fm = am + h * e / nl; /* foot = a - h n, n = (1, 0, -e)/nl; its p-coordinate is not needed */
+    return fm > 0.0 && fq >= t0 * fm && fq <= t1 * fm;
+}
+
+/* does the cone reach cell (c, j) of `face` (g cells per side)?  Cell grown by 0.01 cell; edge cells stretch to
+ * TRT_POINTGRID_EDGE since the look-up clamps into them. */
+TRT_HD int trt_pointgrid_reaches(const trt_pointgrid_cone *s, int face, int c, int j, int g)
+{
+    if (s->everywhere != 0.0)
+        return 1;
+    const int k = face >> 1;
+    const double sg = (face & 1) ? -1.0 : 1.0;
+    /* the cone's axis in the face's frame: (u, v, major), major > 0 on the face */
+    const double au = k == 0 ? s->a[1] : (k == 1 ? s->a[2] : s->a[0]); /* axis (k+1) % 3 */
+    const double av = k == 0 ? s->a[2] : (k == 1 ? s->a[0] : s->a[1]); /* axis (k+2) % 3 */
+    const double am = sg * (k == 0 ? s->a[0] : (k == 1 ? s->a[1] : s->a[2]));
+    const double step = 2.0 / (double)g;
+    const double u0 = c == 0 ? -TRT_POINTGRID_EDGE : -1.0 + ((double)c - 0.01) * step;
+    const double u1 = c == g - 1 ? TRT_POINTGRID_EDGE : -1.0 + ((double)c + 1.01) * step;
+    const double v0 = j == 0 ? -TRT_POINTGRID_EDGE : -1.0 + ((double)j - 0.01) * step;
+    const double v1 = j == g - 1 ? TRT_POINTGRID_EDGE : -1.0 + ((double)j + 1.01) * step;
+    if (am > 0.0 && au >= u0 * am && au <= u1 * am && av >= v0 * am && av <= v1 * am)
+        return 1; /* the axis itself points into the cell */
+    const double cu[4] = {u0, u1, u1, u0}, cv[4] = {v0, v0, v1, v1};
+    for (int q = 0; q < 4; q++) /* a corner inside the cone: cos(angle) >= cos(half-angle) */
+        if ((au * cu[q] + av * cv[q] + am) / __builtin_sqrt(cu[q] * cu[q] + cv[q] * cv[q] + 1.0) >= s->cos_a)
+            return 1;
+    return trt_cone_near_edge(au, av, am, s->sin_a, u0, v0, v1) || trt_cone_near_edge(au, av, am, s->sin_a, u1, v0, v1) ||
+           trt_cone_near_edge(av, au, am, s->sin_a, v0, u0, u1) || trt_cone_near_edge(av, au, am, s->sin_a, v1, u0, u1);
+}
+
+/* Directional light with to-light direction `to_light` (TRT.c:903-904; normalised here).  Fills G and one disc per
+ * sphere (`discs` must hold n).  cs: the culling table's scene constants (shift and bounds). */
+static inline void trt_dirgrid_prepare(const double *spheres, int n, const trt_cull_scene *cs, const double to_light[3], int g, trt_dirgrid *G,
+                                       trt_dirgrid_disc *discs)
 {
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
     const double reach = (double)cs->cn + (double)cs->rm;
@@ -132,28 +204,29 @@ static inline long trt_dirgrid_build(const double *spheres, int n, const trt_cul
     const double E = 0x1p-37 * M * M, delta = 3e-6 * rg;
     /* orthonormal basis across the light direction, in double; the look-up uses its FP32 rounding */
     double d[3] = {to_light[0], to_light[1], to_light[2]};
-    const double dl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const double dl = __builtin_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     for (int k = 0; k < 3; k++)
         d[k] /= dl;
     int thin = 0;
     for (int k = 1; k < 3; k++)
-        if (fabs(d[k]) < fabs(d[thin]))
+        if (__builtin_fabs(d[k]) < __builtin_fabs(d[thin]))
             thin = k;
     double t[3] = {0, 0, 0};
     t[thin] = 1.0;
     double e1[3] = {d[1] * t[2] - d[2] * t[1], d[2] * t[0] - d[0] * t[2], d[0] * t[1] - d[1] * t[0]};
-    const double e1l = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    const double e1l = __builtin_sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
     for (int k = 0; k < 3; k++)
         e1[k] /= e1l;
     const double e2[3] = {d[1] * e1[2] - d[2] * e1[1], d[2] * e1[0] - d[0] * e1[2], d[0] * e1[1] - d[1] * e1[0]};
-    /* discs: centre in plane coordinates, radius rho + delta */
+    /* discs in plane coordinates: centre, radius rho + delta */
     double lo[2] = {0, 0}, hi[2] = {0, 0};
     for (int i = 0; i < n; i++)
     {
         const double *s = spheres + 9 * i;
         const double C[3] = {s[0] - cs->c0[0], s[1] - cs->c0[1], s[2] - cs->c0[2]};
         const double pu = C[0] * e1[0] + C[1] * e1[1] + C[2] * e1[2], pv = C[0] * e2[0] + C[1] * e2[1] + C[2] * e2[2];
-        const double rad = sqrt(s[3] * s[3] + E) + delta;
+        const double rad = __builtin_sqrt(s[3] * s[3] + E) + delta;
+        discs[i].pu = pu, discs[i].pv = pv, discs[i].rad = rad;
         lo[0] = (i == 0 || pu - rad < lo[0]) ? pu - rad : lo[0];
         hi[0] = (i == 0 || pu + rad > hi[0]) ? pu + rad : hi[0];
         lo[1] = (i == 0 || pv - rad < lo[1]) ? pv - rad : lo[1];
@@ -177,117 +250,27 @@ static inline long trt_dirgrid_build(const double *spheres, int n, const trt_cul
     G->rg2 = (float)(rg * rg * (1.0 - 1e-6));
     G->g = g;
     G->words = words;
-    for (long i = 0; i < (long)g * g * words; i++)
-        masks[i] = 0;
-    long bits = 0;
     const double inv = (double)G->inv_cell, u0 = (double)G->u0, v0 = (double)G->v0; /* the look-up's own constants */
     for (int i = 0; i < n; i++)
-    {
-        const double *s = spheres + 9 * i;
-        const double C[3] = {s[0] - cs->c0[0], s[1] - cs->c0[1], s[2] - cs->c0[2]};
-        const double pu = ((C[0] * e1[0] + C[1] * e1[1] + C[2] * e1[2]) - u0) * inv;
-        const double pv = ((C[0] * e2[0] + C[1] * e2[1] + C[2] * e2[2]) - v0) * inv;
-        const double rad = (sqrt(s[3] * s[3] + E) + delta) * inv; /* in cells */
-        int i0 = (int)floor(pu - rad - 0.01), i1 = (int)floor(pu + rad + 0.01);
-        int j0 = (int)floor(pv - rad - 0.01), j1 = (int)floor(pv + rad + 0.01);
-        i0 = i0 < 0 ? 0 : i0, j0 = j0 < 0 ? 0 : j0, i1 = i1 > g - 1 ? g - 1 : i1, j1 = j1 > g - 1 ? g - 1 : j1;
-        for (int j = j0; j <= j1; j++)
-            for (int c = i0; c <= i1; c++)
-            {
-                /* distance from the disc's centre to the cell grown by 0.01 */
-                const double nx = pu < c - 0.01 ? c - 0.01 - pu : (pu > c + 1.01 ? pu - (c + 1.01) : 0.0);
-                const double ny = pv < j - 0.01 ? j - 0.01 - pv : (pv > j + 1.01 ? pv - (j + 1.01) : 0.0);
-                if (nx * nx + ny * ny <= rad * rad)
-                {
-                    trt_lightgrid_set(masks + ((long)j * g + c) * words, i);
-                    bits++;
-                }
-            }
+    { /* to cell units */
+        discs[i].pu = (discs[i].pu - u0) * inv;
+        discs[i].pv = (discs[i].pv - v0) * inv;
+        discs[i].rad = discs[i].rad * inv;
     }
-    return bits;
 }
 
-/* [lo, hi] = the part of the arc [centre - half, centre + half] (angles, mod 2 pi) inside [-limit, limit]; returns 0 if none.
- * Two separate pieces are merged into their hull (conservative). */
-static inline int trt_arc_clip(double centre, double half, double limit, double *lo, double *hi)
-{
-    int any = 0;
-    for (int k = -1; k <= 1; k++)
-    {
-        const double a = centre - half + 6.283185307179586 * k, b = centre + half + 6.283185307179586 * k;
-        const double l = a > -limit ? a : -limit, h = b < limit ? b : limit;
-        if (l <= h)
-        {
-            *lo = (!any || l < *lo) ? l : *lo;
-            *hi = (!any || h > *hi) ? h : *hi;
-            any = 1;
-        }
-    }
-    return any;
-}
-
-/* smallest angle between the unit vector a and the arc of the great circle from unit p to unit q (less than pi apart) */
-static inline double trt_angle_to_arc(const double a[3], const double p[3], const double q[3])
-{
-    double nrm[3] = {p[1] * q[2] - p[2] * q[1], p[2] * q[0] - p[0] * q[2], p[0] * q[1] - p[1] * q[0]};
-    const double nl = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-    const double dp = a[0] * p[0] + a[1] * p[1] + a[2] * p[2], dq = a[0] * q[0] + a[1] * q[1] + a[2] * q[2];
-    double best = acos(dp > 1.0 ? 1.0 : (dp < -1.0 ? -1.0 : dp));
-    const double aq = acos(dq > 1.0 ? 1.0 : (dq < -1.0 ? -1.0 : dq));
-    best = aq < best ? aq : best;
-    if (nl > 1e-300)
-    {
-        for (int k = 0; k < 3; k++)
-            nrm[k] /= nl;
-        const double h = a[0] * nrm[0] + a[1] * nrm[1] + a[2] * nrm[2];
-        const double f[3] = {a[0] - h * nrm[0], a[1] - h * nrm[1], a[2] - h * nrm[2]}; /* foot of a in the arc's plane */
-        /* the foot lies on the arc iff it is on q's side of p and on p's side of q (within the plane) */
-        const double cp[3] = {p[1] * f[2] - p[2] * f[1], p[2] * f[0] - p[0] * f[2], p[0] * f[1] - p[1] * f[0]};
-        const double cq[3] = {f[1] * q[2] - f[2] * q[1], f[2] * q[0] - f[0] * q[2], f[0] * q[1] - f[1] * q[0]};
-        if (cp[0] * nrm[0] + cp[1] * nrm[1] + cp[2] * nrm[2] >= 0.0 && cq[0] * nrm[0] + cq[1] * nrm[1] + cq[2] * nrm[2] >= 0.0)
-        {
-            const double ah = fabs(h) > 1.0 ? 1.0 : fabs(h);
-            best = asin(ah) < best ? asin(ah) : best;
-        }
-    }
-    return best;
-}
-
-/* smallest angle between the unit vector (au, av, am) (face frame, am along the face's axis) and the directions
- * (u, v, 1), u in [u0, u1], v in [v0, v1] */
-static inline double trt_angle_to_cell(double au, double av, double am, double u0, double u1, double v0, double v1)
-{
-    if (am > 0.0 && au >= u0 * am && au <= u1 * am && av >= v0 * am && av <= v1 * am)
-        return 0.0;
-    const double a[3] = {au, av, am};
-    const double cu[4] = {u0, u1, u1, u0}, cv[4] = {v0, v0, v1, v1};
-    double c[4][3];
-    for (int k = 0; k < 4; k++)
-    {
-        const double l = sqrt(cu[k] * cu[k] + cv[k] * cv[k] + 1.0);
-        c[k][0] = cu[k] / l, c[k][1] = cv[k] / l, c[k][2] = 1.0 / l;
-    }
-    double best = 4.0;
-    for (int k = 0; k < 4; k++)
-    {
-        const double t = trt_angle_to_arc(a, c[k], c[(k + 1) & 3]);
-        best = t < best ? t : best;
-    }
-    return best;
-}
-
-/* Point light at `light` (TRT.c:930).  `masks` must hold 6*g*g*words words. */
-static inline long trt_pointgrid_build(const double *spheres, int n, const trt_cull_scene *cs, const double light[3], int g, trt_pointgrid *G,
-                                       unsigned long long *masks)
+/* Point light at `light` (TRT.c:930).  Fills G and one cone per sphere (`cones` must hold n). */
+static inline void trt_pointgrid_prepare(const double *spheres, int n, const trt_cull_scene *cs, const double light[3], int g, trt_pointgrid *G,
+                                         trt_pointgrid_cone *cones)
 {
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
     const double reach = (double)cs->cn + (double)cs->rm;
     const double lc[3] = {light[0] - cs->c0[0], light[1] - cs->c0[1], light[2] - cs->c0[2]};
-    const double away = sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]); /* light to the scene's centre */
+    const double away = __builtin_sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]); /* light to the scene's centre */
     const double rg = TRT_LIGHTGRID_RANGE * (reach + away) + 1.0;
     const double M = rg + away + reach;
     const double E = 0x1p-37 * M * M, near = 0.02 + 4e-6 * rg;
-    const double grow = 1e-5, edge = 0.7853981633974483 + 1e-4; /* cone growth; face half-angle past its edges */
+    const double sin_grow = 1.0000000000e-5, cos_grow = 0.99999999995; /* sin and cos of the 1e-5 rad the cones grow by */
     for (int k = 0; k < 3; k++)
         G->l[k] = light[k];
     G->half_g = (float)(0.5 * g);
@@ -295,62 +278,71 @@ static inline long trt_pointgrid_build(const double *spheres, int n, const trt_c
     G->rg2 = (float)(rg * rg * (1.0 - 1e-6));
     G->g = g;
     G->words = words;
-    const long cells = 6L * g * g;
-    for (long i = 0; i < cells * words; i++)
-        masks[i] = 0;
-    long bits = 0;
     for (int i = 0; i < n; i++)
     {
         const double *s = spheres + 9 * i;
         const double a[3] = {s[0] - light[0], s[1] - light[1], s[2] - light[2]};
-        const double D = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-        const double rho = sqrt(s[3] * s[3] + E) + 0x1p-45 * M;
-        if (!(D > rho + near) || !(rho / D < 0.999999))
-        { /* the light is inside or next to the sphere: every ray may meet it */
-            for (long c = 0; c < cells; c++)
-                trt_lightgrid_set(masks + c * words, i);
-            bits += cells;
+        const double D = __builtin_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        const double rho = __builtin_sqrt(s[3] * s[3] + E) + 0x1p-45 * M;
+        trt_pointgrid_cone *c = cones + i;
+        c->everywhere = (!(D > rho + near) || !(rho / D < 0.999999)) ? 1.0 : 0.0; /* the light is inside or next to the sphere */
+        if (c->everywhere != 0.0)
+        {
+            c->a[0] = c->a[1] = c->a[2] = 0.0;
+            c->sin_a = 1.0, c->cos_a = 0.0;
             continue;
         }
-        const double alpha = asin(rho / D) + grow, sa = sin(alpha);
-        for (int face = 0; face < 6; face++)
-        {
-            const int k = face >> 1;
-            const double sg = (face & 1) ? -1.0 : 1.0;
-            /* the cone's axis in the face's frame: (u, v, major), major > 0 on the face */
-            const double au = a[(k + 1) % 3] / D, av = a[(k + 2) % 3] / D, am = sg * a[k] / D;
-            double range[2][2];
-            int hit = 1;
-            for (int c = 0; c < 2 && hit; c++)
+        for (int k = 0; k < 3; k++)
+            c->a[k] = a[k] / D;
+        const double sn = rho / D, cn = __builtin_sqrt(1.0 - sn * sn);
+        const double sg = sn * cos_grow + cn * sin_grow + 1e-12, cg = cn * cos_grow - sn * sin_grow - 1e-12; /* half-angle + 1e-5 rad */
+        c->sin_a = sg < 1.0 ? sg : 1.0;
+        c->cos_a = cg > 0.0 ? cg : 0.0;
+        if (!(cg > 0.0)) /* grown past 90 degrees: treat like a sphere next to the light */
+            c->everywhere = 1.0;
+    }
+}
+
+/* Host reference builders (tests; the library builds the same tables on the device).  Return the bits set. */
+static inline long trt_dirgrid_build(const double *spheres, int n, const trt_cull_scene *cs, const double to_light[3], int g, trt_dirgrid *G,
+                                     unsigned long long *masks, trt_dirgrid_disc *discs)
+{
+    trt_dirgrid_prepare(spheres, n, cs, to_light, g, G, discs);
+    const int words = G->words;
+    long bits = 0;
+    for (long cell = 0; cell < (long)g * g; cell++)
+    {
+        unsigned long long *m = masks + cell * words;
+        for (int w = 0; w < words; w++)
+            m[w] = 0;
+        for (int i = 0; i < n; i++)
+            if (trt_dirgrid_reaches(discs + i, (int)(cell % g), (int)(cell / g)))
             {
-                const double ac = c == 0 ? au : av;          /* project along the other face axis: a wedge in the (ac, am) plane */
-                const double len = sqrt(ac * ac + am * am);  /* sin(beta) = sin(alpha) / len */
-                double lo = -edge, hi = edge;
-                if (sa < len)
-                    hit = trt_arc_clip(atan2(ac, am), asin(sa / len) + 1e-9, edge, &lo, &hi);
-                range[c][0] = (tan(lo) + 1.0) * 0.5 * g;
-                range[c][1] = (tan(hi) + 1.0) * 0.5 * g;
+                trt_lightgrid_set(m, i);
+                bits++;
             }
-            if (!hit)
-                continue;
-            int i0 = (int)floor(range[0][0] - 0.01), i1 = (int)floor(range[0][1] + 0.01);
-            int j0 = (int)floor(range[1][0] - 0.01), j1 = (int)floor(range[1][1] + 0.01);
-            i0 = i0 < 0 ? 0 : i0, j0 = j0 < 0 ? 0 : j0, i1 = i1 > g - 1 ? g - 1 : i1, j1 = j1 > g - 1 ? g - 1 : j1;
-            /* inside the box of the two wedges: keep the cells the cone really reaches (cell grown by 0.01, and the
-             * edge cells stretched past the face's edge, as the look-up clamps into them) */
-            const double te = tan(edge), step = 2.0 / g;
-            for (int j = j0; j <= j1; j++)
-                for (int c = i0; c <= i1; c++)
-                {
-                    const double cu0 = c == 0 ? -te : -1.0 + (c - 0.01) * step, cu1 = c == g - 1 ? te : -1.0 + (c + 1.01) * step;
-                    const double cv0 = j == 0 ? -te : -1.0 + (j - 0.01) * step, cv1 = j == g - 1 ? te : -1.0 + (j + 1.01) * step;
-                    if (trt_angle_to_cell(au, av, am, cu0, cu1, cv0, cv1) <= alpha + 1e-9)
-                    {
-                        trt_lightgrid_set(masks + (((long)face * g + j) * g + c) * words, i);
-                        bits++;
-                    }
-                }
-        }
+    }
+    return bits;
+}
+
+static inline long trt_pointgrid_build(const double *spheres, int n, const trt_cull_scene *cs, const double light[3], int g, trt_pointgrid *G,
+                                       unsigned long long *masks, trt_pointgrid_cone *cones)
+{
+    trt_pointgrid_prepare(spheres, n, cs, light, g, G, cones);
+    const int words = G->words;
+    long bits = 0;
+    for (long cell = 0; cell < 6L * g * g; cell++)
+    {
+        unsigned long long *m = masks + cell * words;
+        for (int w = 0; w < words; w++)
+            m[w] = 0;
+        const int face = (int)(cell / ((long)g * g)), j = (int)((cell / g) % g), c = (int)(cell % g);
+        for (int i = 0; i < n; i++)
+            if (trt_pointgrid_reaches(cones + i, face, c, j, g))
+            {
+                trt_lightgrid_set(m, i);
+                bits++;
+            }
     }
     return bits;
 }

@@ -68,6 +68,7 @@ SYMBOLS = {
     "trt_set_kernel": (_I, [_VP, _I]),
     "trt_set_work_units": (_I, [_VP, _I]),
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
+    "trt_read_light_grid": (C.c_long, [_VP, _I, _I, _VP, C.c_size_t]),
     "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
     "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
     "trt_probe_rays": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
@@ -152,6 +153,14 @@ class Context:
     def set_light_grids(self, directional_cells, point_cells):
         """cells per side of the light-space candidate tables; 0, 0 = off (trt_set_light_grids)"""
         _check(lib().trt_set_light_grids(self._h, directional_cells, point_cells))
+
+    def read_light_grid(self, point_light, index, words):
+        """one light's device-built candidate table as uint64 words (trt_read_light_grid)"""
+        out = np.zeros(words, dtype=np.uint64)
+        got = lib().trt_read_light_grid(self._h, int(point_light), index, out.ctypes.data, words)
+        if got < 0:
+            _check(int(got))
+        return out[:got]
 
     def render_device(self, camera_array, rows, bounce_limit, rays_per_pixel, device_ptr, capacity_bytes):
         cam = camera_struct(camera_array)

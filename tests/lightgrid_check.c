@@ -71,7 +71,9 @@ void dirgrid_check(const double *spheres, int n, const double *rays, size_t n_ra
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
     unsigned long long *masks = (unsigned long long *)malloc(sizeof(unsigned long long) * (size_t)g * g * words);
     trt_dirgrid G;
-    st->bits_set = (unsigned long long)trt_dirgrid_build(spheres, n, &cs, rays + 3, g, &G, masks);
+    trt_dirgrid_disc *discs = (trt_dirgrid_disc *)malloc(sizeof(trt_dirgrid_disc) * (size_t)(n ? n : 1));
+    st->bits_set = (unsigned long long)trt_dirgrid_build(spheres, n, &cs, rays + 3, g, &G, masks, discs);
+    free(discs);
     st->cells = (unsigned long long)g * g;
     /* the clamp relies on an empty border */
     for (int j = 0; j < g; j++)
@@ -159,7 +161,9 @@ void pointgrid_check(const double *spheres, int n, const double *light, const do
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
     unsigned long long *masks = (unsigned long long *)malloc(sizeof(unsigned long long) * 6 * (size_t)g * g * words);
     trt_pointgrid G;
-    st->bits_set = (unsigned long long)trt_pointgrid_build(spheres, n, &cs, light, g, &G, masks);
+    trt_pointgrid_cone *cones = (trt_pointgrid_cone *)malloc(sizeof(trt_pointgrid_cone) * (size_t)(n ? n : 1));
+    st->bits_set = (unsigned long long)trt_pointgrid_build(spheres, n, &cs, light, g, &G, masks, cones);
+    free(cones);
     st->cells = 6ull * g * g;
     const double near = 0.02 + 4e-6 * sqrt((double)G.rg2);
     unsigned group_max = 0;
@@ -200,4 +204,31 @@ void pointgrid_check(const double *spheres, int n, const double *light, const do
     }
     free(masks);
     free(table);
+}
+
+/* The tables themselves, as the host reference builders make them (the GPU tests compare the device-built tables).
+ * kind 0: directional light with to-light direction v, masks g*g*words; kind 1: point light at v, masks 6*g*g*words. */
+long lightgrid_host_table(const double *spheres, int n, int kind, const double *v, int g, unsigned long long *masks)
+{
+    const int padded = trt_cull_padded(n, 8);
+    float *table = (float *)malloc(sizeof(float) * 4 * (size_t)(padded ? padded : 1));
+    trt_cull_scene cs;
+    trt_cull_build(spheres, n, 8, table, &cs);
+    free(table);
+    long bits;
+    if (kind == 0)
+    {
+        trt_dirgrid G;
+        trt_dirgrid_disc *discs = (trt_dirgrid_disc *)malloc(sizeof(trt_dirgrid_disc) * (size_t)(n ? n : 1));
+        bits = trt_dirgrid_build(spheres, n, &cs, v, g, &G, masks, discs);
+        free(discs);
+    }
+    else
+    {
+        trt_pointgrid G;
+        trt_pointgrid_cone *cones = (trt_pointgrid_cone *)malloc(sizeof(trt_pointgrid_cone) * (size_t)(n ? n : 1));
+        bits = trt_pointgrid_build(spheres, n, &cs, v, g, &G, masks, cones);
+        free(cones);
+    }
+    return bits;
 }

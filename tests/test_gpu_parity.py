@@ -413,3 +413,43 @@ def test_light_space_tables_never_change_a_frame(ctx, cells):
             assert np.array_equal(bits(got), bits(want)), (cells, len(scene.spheres))
     finally:
         ctx.set_light_grids(128, 64)
+
+
+def test_device_built_light_tables_equal_the_host_reference_builder(ctx):
+    """The library marks the cells of the light-space tables on the GPU (one thread per cell); tests/test_lightgrid.py proves
+    the HOST builder conservative.  Both run the same predicates (+ - * / sqrt only), so the tables must agree word for word."""
+    import os
+    import subprocess
+    build = os.path.join(T.ROOT, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    so = os.path.join(build, "liblightgridcheck.so")
+    inc = os.path.join(T.ROOT, "terminalraytracer_amd", "csrc")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-I" + inc, "-o", so,
+                           os.path.join(T.ROOT, "tests", "lightgrid_check.c"), "-lm"])
+    lib = C.CDLL(so)
+    lib.lightgrid_host_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.lightgrid_host_table.restype = C.c_long
+    base = S.synth_scene(40, T.sky("synth"), T.bench_camera(32, 18), seed=5)
+    c, r = base.spheres[3, :3], base.spheres[3, 3]
+    lights = np.array([list(c + [0.0, r * 0.999, 0.0]) + [0.2, 1.0, 0.3, 9.0], list(c + [r * (1 + 1e-9), 0.0, 0.0]) + [1.0, 0.3, 0.2, 9.0],
+                       [0.3, 7.0, -2.0, 1.0, 1.0, 1.0, 50.0], [40.0, 3.0, 11.0, 1.0, 1.0, 1.0, 900.0]])
+    dirs = np.array([[0.0, -1.0, 0.0, 0.5, 0.5, 0.5], [1.0, -1e-9, 0.0, 0.3, 0.2, 0.1], [-0.3, -0.8, 0.55, 0.2, 0.3, 0.4]])
+    scenes = [S.synth_scene(64, T.sky("synth"), T.bench_camera(32, 18)), S.synth_scene(256, T.sky("synth"), T.bench_camera(32, 18)),
+              S.SceneData(base.spheres, base.ground, dirs, lights, base.camera, base.sky)]
+    try:
+        for scene in scenes:
+            sph = np.ascontiguousarray(scene.spheres, dtype=np.float64)
+            n, words = len(sph), max(1, (len(sph) + 63) // 64)
+            for gd, gp in ((128, 64), (19, 5)):
+                ctx.set_scene(scene)
+                ctx.set_light_grids(gd, gp)
+                for kind, count, g, cells in ((0, len(scene.dir_lights), gd, gd * gd), (1, len(scene.point_lights), gp, 6 * gp * gp)):
+                    for i in range(count):
+                        v = np.ascontiguousarray(-scene.dir_lights[i, :3] if kind == 0 else scene.point_lights[i, :3], dtype=np.float64)
+                        want = np.zeros(cells * words, dtype=np.uint64)
+                        bits = lib.lightgrid_host_table(sph.ctypes.data, n, kind, v.ctypes.data, g, want.ctypes.data)
+                        got = ctx.read_light_grid(kind, i, cells * words)
+                        assert bits > 0 and len(got) == cells * words
+                        assert np.array_equal(got, want), (n, kind, i, g, int((got != want).sum()))
+    finally:
+        ctx.set_light_grids(128, 64)

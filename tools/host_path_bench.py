@@ -19,3 +19,12 @@ for _ in range(n):
     call()
 dt = (time.perf_counter() - t0) / n
 print(f"trt_render_frame host-in/host-out: {dt * 1e3:.2f} ms/frame  ({px.nbytes / 1e6:.1f} MB framebuffer copied back per frame)")
+
+# the same with a sphere moving every frame: the library has to rebuild its light-space tables per call
+t0 = time.perf_counter()
+for i in range(n):
+    scene.spheres[0, 1] += 1e-3
+    sc = scene.as_scene()
+    call()
+dt = (time.perf_counter() - t0) / n
+print(f"... with one sphere moved before every call (tables rebuilt): {dt * 1e3:.2f} ms/frame")
