@@ -1,0 +1,62 @@
+"""Randomised parity campaign on the GPU box: many fuzzed scenes (tests/test_gpu_parity._fuzz_scene: 0..100 spheres, exact ties,
+degenerate radii, lights on sphere surfaces, cameras inside spheres, tilted grounds) rendered by the production kernel and
+compared bit for bit with the oracle.  usage: python tools/fuzz_campaign.py [first_seed] [count]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import support as T
+from terminalraytracer_amd import hip
+import test_gpu_parity as P
+
+from terminalraytracer_amd import scenes as S
+
+
+def wide_scene(rng, w, h):
+    """Scenes of any size anywhere: spheres spread over 0.1..100 units, the whole scene up to 1e3 from the origin, lights near,
+    far and inside the cloud, the camera outside looking at the cloud (so that ground points near the horizon, far beyond the
+    light tables' range, are in view)."""
+    n = int(rng.choice([1, 3, 17, 64, 65, 130]))
+    scale = 10.0 ** rng.uniform(-1, 2)
+    shift = rng.normal(size=3) * 10.0 ** rng.uniform(-1, 3)
+    sph = np.zeros((n, 9))
+    sph[:, :3] = rng.normal(size=(n, 3)) * scale + shift
+    sph[:, 3] = rng.uniform(0.02, 0.4, n) * scale
+    sph[:, 4:7] = rng.uniform(0, 1, (n, 3))
+    sph[:, 7] = rng.choice([0.0, 0.5, 1.0], n)
+    sph[:, 8] = 100.0
+    ground = S.demo_ground().copy()
+    ground[0:3] = shift + np.array([0.0, -2.0 * scale, 0.0])
+    ground[9] = rng.choice([0.0, 0.5])
+    nd, npt = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    dl = np.concatenate([rng.normal(size=(nd, 3)) * [1, 1, 1] - [0, 1.0, 0], rng.uniform(0, 1.2, (nd, 3))], axis=1)
+    pl = np.concatenate([shift + rng.normal(size=(npt, 3)) * scale * 10.0 ** rng.uniform(-1, 1.5, (npt, 1)), rng.uniform(0, 1.2, (npt, 3)),
+                         rng.uniform(0.1, 30, (npt, 1)) * scale * scale], axis=1)
+    cam = T.bench_camera(w, h, float(rng.choice([0.0, 0.5, 2.5, 10.0])))
+    cam[9:12] = cam[9:12] * scale * rng.uniform(0.3, 3.0) + shift   # the stored orbit looks at the origin from ~10 units away
+    return S.SceneData(sph, ground, dl.reshape(-1, 6), pl.reshape(-1, 7), cam, T.sky("synth"))
+
+
+first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
+make = wide_scene if len(sys.argv) > 3 and sys.argv[3] == "wide" else P._fuzz_scene
+bad = 0
+with hip.Context(0) as ctx:
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(seed)
+        w, h = int(rng.integers(8, 160)), int(rng.integers(4, 90))
+        b, spp = int(rng.integers(1, 13)), int(rng.choice([1, 3, 10]))
+        scene = make(rng, w, h)
+        with np.errstate(all="ignore"):
+            want, st = T.oracle_render(scene, w, h, b, spp)
+        got = P.render(ctx, scene, w, h, b, spp)
+        finite = np.isfinite(want)
+        ok = np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(P.bits(got[finite]), P.bits(want[finite]))
+        if not ok:
+            bad += 1
+            diff = int((P.bits(got) != P.bits(want)).sum())
+            print(f"seed {seed}: MISMATCH {diff} values differ  ({w}x{h}, {len(scene.spheres)} spheres, B{b}, spp{spp}, "
+                  f"{len(scene.dir_lights)}+{len(scene.point_lights)} lights)", flush=True)
+        if (seed - first) % 50 == 49:
+            print(f"... {seed - first + 1} scenes, {bad} mismatches", flush=True)
+print(f"fuzz campaign: {count} scenes from seed {first}: {bad} mismatches")
+sys.exit(1 if bad else 0)
