@@ -150,6 +150,12 @@ int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *static_lds_by
  * device instructions sequences the kernels use (host arrays in/out). */
 int trt_selftest_div_sqrt(trt_context *ctx, const double *a, const double *b, size_t n, double *quot, double *root);
 
+/* The kernels normalise vectors (TRT.c:439-450) with one shared reciprocal refinement for the three divisions and a
+ * square root without the compiler's range handling whenever a whole wave's operands are far from the ends of the
+ * exponent range.  This entry runs that code (`fast`) and the compiler's plain `/` and sqrt (`reference`) on n
+ * records {x, y, z, w}: out = {unit(x,y,z), sqrt(w)}.  The two outputs must be identical bit for bit. */
+int trt_selftest_unit(trt_context *ctx, const double *xyzw, size_t n, double *fast, double *reference);
+
 /* Single-ray probe for tests: closest hit of TRT.c:793 for n rays (host arrays): obj[n],
  * point[3n], normal[3n], material[5n] (colour, reflectivity, specularity); lit[3n] = colour after
  * the lighting of TRT.c:894 for hits. */

@@ -942,6 +942,26 @@ extern "C" int trt_selftest_div_sqrt(trt_context *ctx, const double *a, const do
     return TRT_OK;
 }
 
+extern "C" int trt_selftest_unit(trt_context *ctx, const double *xyzw, size_t n, double *fast, double *reference)
+{
+    if (!ctx || !xyzw || !fast || !reference)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (n == 0)
+        return TRT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceBuffer<double> buf;
+    HIP_TRY(buf.reserve(12 * n));
+    double *dv = buf.ptr, *df = buf.ptr + 4 * n, *dr = buf.ptr + 8 * n;
+    HIP_TRY(hipMemcpy(dv, xyzw, 4 * n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(trt::unit_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dv, (long)n, df, dr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(fast, df, 4 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(reference, dr, 4 * n * sizeof(double), hipMemcpyDeviceToHost));
+    buf.release();
+    return TRT_OK;
+}
+
 extern "C" int trt_probe_rays(trt_context *ctx, const Ray *rays, size_t n, int *obj, double *point, double *normal,
                               double *material, double *lit)
 {

@@ -28,10 +28,87 @@ TRT_DEV d3 add(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 TRT_DEV d3 mulc(d3 a, d3 b) { return d3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 TRT_DEV d3 scale(d3 a, double s) { return d3{a.x * s, a.y * s, a.z * s}; }
 
+// ---- square root and the three divisions of a normalisation, without the compiler's range handling ----
+// hipcc expands an FP64 sqrt into v_rsq_f64 + 9 multiply/FMA steps wrapped in scaling for tiny arguments and a class test
+// for 0/inf, and every FP64 division into two v_div_scale, v_rcp_f64, 7 FMA/mul steps, v_div_fmas and v_div_fixup.  For
+// arguments whose exponents are nowhere near the ends of the range the wrappers do nothing: v_div_scale returns its
+// operand and VCC = 0 (so v_div_fmas is a plain FMA), v_div_fixup passes a finite quotient through, the sqrt scaling is off.
+// The functions below run the SAME arithmetic steps without the wrappers when EVERY active lane of the wave is inside
+// that window, and the compiler's full sequence otherwise (one wave-uniform branch), so the results are those of
+// `/` and __builtin_sqrt bit for bit; trt_selftest_unit compares them on the device.  TRT_LEAN_MATH=0 turns this off.
+#ifndef TRT_LEAN_MATH
+#define TRT_LEAN_MATH 1
+#endif
+
+TRT_DEV unsigned hi32(double x) { return (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32); }
+TRT_DEV unsigned lo32(double x) { return (unsigned)__builtin_bit_cast(unsigned long long, x); }
+
+// positive, finite, biased exponent in [723, 1323): 2^-300 <= x < 2^300
+TRT_DEV bool mid_range(double x) { return hi32(x) - (723u << 20) < (600u << 20); }
+
+TRT_DEV double sqrt_exact(double x) // == __builtin_sqrt(x)
+{
+#if TRT_LEAN_MATH
+    if (!__any(!mid_range(x)))
+    { // the steps of the compiler's expansion between its scaling and its 0/inf select
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, h = y * 0.5;
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        double d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        d = __builtin_fma(-g, g, x);
+        return __builtin_fma(d, h, g);
+    }
+#endif
+    return __builtin_sqrt(x);
+}
+
 // TRT.c:439-450: sqrt of the squared length, then THREE divisions, only when length > 1e-4
 TRT_DEV d3 unit(d3 a)
 {
-    double len = __builtin_sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    const double len = sqrt_exact(a.x * a.x + a.y * a.y + a.z * a.z);
+    if (len > 0.0001)
+    {
+#if TRT_LEAN_MATH
+        // a numerator takes the short way if it is zero (the quotient is that zero, sign included) or mid-range in
+        // magnitude; with len mid-range too, no quotient is near overflow or underflow
+        const unsigned ax = hi32(a.x) & 0x7fffffffu, ay = hi32(a.y) & 0x7fffffffu, az = hi32(a.z) & 0x7fffffffu;
+        const bool ok = mid_range(len) && (ax - (723u << 20) < (600u << 20) || (ax | lo32(a.x)) == 0) &&
+                        (ay - (723u << 20) < (600u << 20) || (ay | lo32(a.y)) == 0) && (az - (723u << 20) < (600u << 20) || (az | lo32(a.z)) == 0);
+        if (!__any(!ok))
+        {
+            // one reciprocal refinement for the three quotients (what the three expansions would each repeat)
+            double r = __builtin_amdgcn_rcp(len);
+            double e = __builtin_fma(-len, r, 1.0);
+            r = __builtin_fma(r, e, r);
+            e = __builtin_fma(-len, r, 1.0);
+            r = __builtin_fma(r, e, r);
+            double q[3] = {a.x, a.y, a.z};
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+            {
+                const double num = q[k];
+                const double q0 = num * r;
+                const double err = __builtin_fma(-len, q0, num);
+                const double quo = __builtin_fma(err, r, q0);
+                q[k] = __builtin_copysign(quo, num); // v_div_fixup gives the quotient the sign of num/len; matters for +-0 only
+            }
+            return d3{q[0], q[1], q[2]};
+        }
+#endif
+        a.x /= len;
+        a.y /= len;
+        a.z /= len;
+    }
+    return a;
+}
+
+// the compiler's own expansions, for trt_selftest_unit
+TRT_DEV d3 unit_reference(d3 a)
+{
+    const double len = __builtin_sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
     if (len > 0.0001)
     {
         a.x /= len;

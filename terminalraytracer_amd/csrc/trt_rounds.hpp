@@ -303,7 +303,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
                     const double disc = b * b - 4.0 * a * cc;
                     if (!(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
                     {
-                        const double t0 = (-b - __builtin_sqrt(disc)) / (2.0 * a);
+                        const double t0 = (-b - sqrt_exact(disc)) / (2.0 * a);
                         if (t0 > 0.0)
                         {
                             const d3 pt = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
@@ -390,7 +390,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
                     const double disc = b * b - 4.0 * a * cc;
                     if (!(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
                     {
-                        const double t0 = (-b - __builtin_sqrt(disc)) / (2.0 * a);
+                        const double t0 = (-b - sqrt_exact(disc)) / (2.0 * a);
                         if (t0 > 0.0)
                         {
                             if (ANY_HIT)

@@ -245,6 +245,20 @@ __global__ void div_sqrt_kernel(const double *a, const double *b, long n, double
     }
 }
 
+// unit() as the kernels use it (shared reciprocal, lean sqrt) next to the compiler's plain expansions; both also return
+// the square root of the first component's magnitude
+__global__ void unit_selftest_kernel(const double *v, long n, double *fast, double *reference)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        const d3 a = d3{v[4 * i], v[4 * i + 1], v[4 * i + 2]};
+        const d3 f = unit(a), r = unit_reference(a);
+        fast[4 * i] = f.x, fast[4 * i + 1] = f.y, fast[4 * i + 2] = f.z, fast[4 * i + 3] = sqrt_exact(v[4 * i + 3]);
+        reference[4 * i] = r.x, reference[4 * i + 1] = r.y, reference[4 * i + 2] = r.z, reference[4 * i + 3] = __builtin_sqrt(v[4 * i + 3]);
+    }
+}
+
 // (int)(c*255) per channel, TRT.c:1157-1163
 __global__ void quantize_kernel(const double *px, long n_values, unsigned char *rgb)
 {

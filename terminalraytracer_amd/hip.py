@@ -68,6 +68,7 @@ SYMBOLS = {
     "trt_set_kernel": (_I, [_VP, _I]),
     "trt_set_work_units": (_I, [_VP, _I]),
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
+    "trt_selftest_unit": (_I, [_VP, _VP, C.c_size_t, _VP, _VP]),
     "trt_read_light_grid": (C.c_long, [_VP, _I, _I, _VP, C.c_size_t]),
     "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
     "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
@@ -153,6 +154,13 @@ class Context:
     def set_light_grids(self, directional_cells, point_cells):
         """cells per side of the light-space candidate tables; 0, 0 = off (trt_set_light_grids)"""
         _check(lib().trt_set_light_grids(self._h, directional_cells, point_cells))
+
+    def selftest_unit(self, xyzw):
+        """(fast, reference): unit(x,y,z) and sqrt(w) by the kernels' lean code and by the compiler's plain expansions"""
+        v = np.ascontiguousarray(xyzw, dtype=np.float64).reshape(-1, 4)
+        fast, ref = np.zeros_like(v), np.zeros_like(v)
+        _check(lib().trt_selftest_unit(self._h, v.ctypes.data, v.shape[0], fast.ctypes.data, ref.ctypes.data))
+        return fast, ref
 
     def read_light_grid(self, point_light, index, words):
         """one light's device-built candidate table as uint64 words (trt_read_light_grid)"""

@@ -453,3 +453,38 @@ def test_device_built_light_tables_equal_the_host_reference_builder(ctx):
                         assert np.array_equal(got, want), (n, kind, i, g, int((got != want).sum()))
     finally:
         ctx.set_light_grids(128, 64)
+
+
+def test_lean_normalisation_and_sqrt_equal_the_plain_operators(ctx):
+    """unit() shares one reciprocal refinement between its three divisions and takes a square root without the compiler's
+    range handling when a whole wave is mid-range, and falls back to the plain operators otherwise (csrc/trt_device.hpp).
+    Both must give the bits of `/` and sqrt: millions of vectors of every kind, laid out so that some waves are uniformly
+    mid-range (short path taken) and others mix in zeros, denormals, huge, tiny, inf and NaN (fallback taken)."""
+    rng = np.random.default_rng(3)
+    n = 1 << 21
+    v = rng.normal(size=(n, 4)) * 10.0 ** rng.uniform(-3, 3, (n, 1))
+    v[:, 3] = np.abs(v[:, 3])
+    blocks = v.reshape(-1, 64, 4)                          # one wave per block of 64 records
+    kinds = rng.integers(0, 8, blocks.shape[0])
+    blocks[kinds == 1, :, 0] = 0.0                         # exact zeros in a component, both signs
+    blocks[kinds == 1, ::2, 1] = -0.0
+    blocks[kinds == 2] *= 1e-160                           # squared length underflows towards denormals
+    blocks[kinds == 3] *= 1e160                            # squared length overflows
+    blocks[kinds == 4, :, 2] *= 1e-120                     # one component far below the others: outside the window
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 4.9e-324, 1e-310, 1.7e308, 1e-4, 1.0000000001e-4, 0.0001])
+    blocks[kinds == 5, ::7, :] = rng.choice(special, (int((kinds == 5).sum()), len(range(0, 64, 7)), 4))
+    blocks[kinds == 6] = np.round(blocks[kinds == 6] * 4) / 4        # many exactly representable quotients and ties
+    blocks[kinds == 7, :, :3] *= 10.0 ** rng.uniform(-89, 89, (int((kinds == 7).sum()), 1, 1))  # around the window's edges (2^+-300)
+    with np.errstate(all="ignore"):
+        fast, ref = ctx.selftest_unit(blocks.reshape(-1, 4))
+        # the plain operators themselves against the host's IEEE arithmetic
+        x = blocks.reshape(-1, 4)
+        length = np.sqrt(x[:, 0] * x[:, 0] + x[:, 1] * x[:, 1] + x[:, 2] * x[:, 2])
+        host = np.where((length > 0.0001)[:, None], x[:, :3] / length[:, None], x[:, :3])
+        host_root = np.sqrt(x[:, 3])
+    same = (bits(fast) == bits(ref)) | (np.isnan(fast) & np.isnan(ref))
+    assert same.all(), (int((~same).sum()), blocks.reshape(-1, 4)[np.argwhere(~same)[0][0]])
+    ok = (bits(ref[:, :3]) == bits(host)) | (np.isnan(ref[:, :3]) & np.isnan(host))
+    assert ok.all(), int((~ok).sum())
+    ok = (bits(ref[:, 3]) == bits(host_root)) | (np.isnan(ref[:, 3]) & np.isnan(host_root))
+    assert ok.all(), int((~ok).sum())
