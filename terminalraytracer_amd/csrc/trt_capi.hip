@@ -130,6 +130,8 @@ struct trt_context
     int rounds_blocks_per_cu = 0;
     size_t occupancy_for_lds = (size_t)-1;
     hipEvent_t ev_chunk[16]; // hand-over of framebuffer chunks to the host copy threads (trt_render_host)
+    hipEvent_t ev_band[4];   // a band of rows is rendered: its copy-out may start (trt_render_host)
+    hipStream_t copy_stream = nullptr;
     int units = 0;  // work units of the production kernel: 0 automatic, 1 pixels, 2 samples
     bool counters_enabled = false;
     unsigned long long last_trips = 0, last_phase2 = 0; // diagnostics of the counting kernel variant
@@ -458,6 +460,9 @@ extern "C" int trt_create(int device, trt_context **out)
     }
     for (int i = 0; i < 16; i++)
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
+    for (int i = 0; i < 4; i++)
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_band[i], hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     HIP_TRY(ctx->d_counters.reserve(kCounterSlots));
     HIP_TRY(ctx->d_queue.reserve(64));
     HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long)));
@@ -488,6 +493,10 @@ extern "C" int trt_destroy(trt_context *ctx)
     }
     for (int i = 0; i < 16; i++)
         (void)hipEventDestroy(ctx->ev_chunk[i]);
+    for (int i = 0; i < 4; i++)
+        (void)hipEventDestroy(ctx->ev_band[i]);
+    if (ctx->copy_stream)
+        (void)hipStreamDestroy(ctx->copy_stream);
     ctx->d_spheres.release();
     ctx->d_dir.release();
     ctx->d_point.release();
@@ -816,24 +825,45 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
         ctx->h_staging_bytes = std::max<size_t>(bytes, 1);
     }
     const double t_begin = host_now_ms();
-    int rc = trt_render_device(ctx, camera, rows, bounce_limit, rays_per_pixel, ctx->d_fb.ptr, bytes);
-    if (rc)
-        return rc;
-    const double t_enqueued = host_now_ms();
-    if (print_host_times())
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const double t_rendered = host_now_ms();
-    // Device -> pinned staging -> the caller's (pageable) buffer, pipelined: the frame goes over PCIe in chunks, an event
-    // marks each chunk, and a few host threads copy chunks out of the staging buffer as they land.
-    const int chunks = (int)std::min<size_t>(16, std::max<size_t>(1, bytes / (4u << 20)));
-    const size_t per = ((bytes + chunks - 1) / chunks + 63) / 64 * 64;
-    for (int i = 0; i < chunks; i++)
+    // A whole frame is rendered in up to four bands of rows: while band b+1 is being rendered, band b crosses PCIe on the
+    // copy stream into pinned staging, chunk by chunk (an event per chunk), and a few host threads copy landed chunks
+    // into the caller's (pageable) buffer.  Shards and small frames are one band.
+    const int local_rows = trt_rowset_rows(rows);
+    const bool whole = rows->tile_first == 0 && rows->tile_step == 1 && rows->tile_rows >= rows->height;
+    const int bands = whole && !ctx->counters_enabled && local_rows >= 256 && bytes >= (32u << 20) ? 4 : 1;
+    const int band_rows = (local_rows + bands - 1) / bands;
+    const size_t row_bytes = (size_t)rows->width * sizeof(Vector);
+    const int chunks_per_band = (int)std::min<size_t>(16 / bands, std::max<size_t>(1, (size_t)band_rows * row_bytes / (4u << 20)));
+    int chunks = 0;
+    size_t chunk_at[16], chunk_len[16];
+    const hipStream_t copy_stream = bands > 1 ? ctx->copy_stream : ctx->stream;
+    for (int b = 0; b < bands; b++)
     {
-        const size_t at = (size_t)i * per, len = at < bytes ? std::min(per, bytes - at) : 0;
-        if (len)
-            HIP_TRY(hipMemcpyAsync((char *)ctx->h_staging + at, (const char *)ctx->d_fb.ptr + at, len, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipEventRecord(ctx->ev_chunk[i], ctx->stream));
+        trt_rowset band = *rows;
+        if (bands > 1)
+            band = trt_rowset{rows->width, rows->height, band_rows, b, bands};
+        const int rows_here = trt_rowset_rows(&band);
+        const size_t at = (size_t)b * band_rows * row_bytes, len = (size_t)rows_here * row_bytes;
+        int rc = trt_render_device(ctx, camera, &band, bounce_limit, rays_per_pixel, (char *)ctx->d_fb.ptr + at, len);
+        if (rc)
+            return rc;
+        if (bands > 1)
+        { // a second stream costs ~0.1 ms of cross-queue hand-over: only where there is something to overlap
+            HIP_TRY(hipEventRecord(ctx->ev_band[b], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(copy_stream, ctx->ev_band[b], 0));
+        }
+        const size_t per = ((len + chunks_per_band - 1) / chunks_per_band + 63) / 64 * 64;
+        for (int i = 0; i < chunks_per_band; i++, chunks++)
+        {
+            chunk_at[chunks] = at + (size_t)i * per;
+            chunk_len[chunks] = (size_t)i * per < len ? std::min(per, len - (size_t)i * per) : 0;
+            if (chunk_len[chunks])
+                HIP_TRY(hipMemcpyAsync((char *)ctx->h_staging + chunk_at[chunks], (const char *)ctx->d_fb.ptr + chunk_at[chunks], chunk_len[chunks],
+                                       hipMemcpyDeviceToHost, copy_stream));
+            HIP_TRY(hipEventRecord(ctx->ev_chunk[chunks], copy_stream));
+        }
     }
+    const double t_enqueued = host_now_ms();
     const int workers = chunks >= 4 ? 4 : 1;
     hipError_t worker_error[4] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess};
     auto drain = [&](int w) {
@@ -846,8 +876,7 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
                 worker_error[w] = e;
                 return;
             }
-            const size_t at = (size_t)i * per, len = at < bytes ? std::min(per, bytes - at) : 0;
-            memcpy((char *)pixels + at, (const char *)ctx->h_staging + at, len);
+            memcpy((char *)pixels + chunk_at[i], (const char *)ctx->h_staging + chunk_at[i], chunk_len[i]);
         }
     };
     if (workers == 1)
@@ -863,10 +892,12 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
     }
     for (int w = 0; w < workers; w++)
         HIP_TRY(worker_error[w]);
+    if (bands > 1)
+        HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (print_host_times())
-        fprintf(stderr, "trt_render_host: enqueue %.3f ms, kernels %.3f ms, copy-out of %zu bytes %.3f ms\n", t_enqueued - t_begin,
-                t_rendered - t_enqueued, bytes, host_now_ms() - t_rendered);
+        fprintf(stderr, "trt_render_host: %d band(s), enqueue %.3f ms, render + copy-out of %zu bytes %.3f ms\n", bands, t_enqueued - t_begin, bytes,
+                host_now_ms() - t_enqueued);
     return TRT_OK;
 }
 
