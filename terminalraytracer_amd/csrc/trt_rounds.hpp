@@ -57,6 +57,8 @@ struct GridView
     int enabled;
 };
 
+static_assert(sizeof(trt_dirgrid) == 8 * kDirGridDoubles && sizeof(trt_pointgrid) == 8 * kPointGridDoubles, "light-table headers in the LDS image");
+
 struct LdsImage
 {
     const float4 *cull;  // culling table {Cx,Cy,Cz,kk}
@@ -73,10 +75,12 @@ struct LdsImage
     const double *b255;  // byte / 255.0
     const double *cam;   // basis x,y,z (9), eye (3), -screen_distance
     const double *jit;   // jitter x[spp], y[spp]
+    const trt_dirgrid *dirgrid;     // headers of the light-space tables (trt_lightgrid.h), per directional light
+    const trt_pointgrid *pointgrid; // per point light
 };
 
 // same layout and size as trt_persistent.hpp (persistent_lds_bytes)
-TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView &cull, const FrameView &f)
+TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView &cull, const FrameView &f, const GridView &grids)
 {
     const int n = s.num_spheres, nd = s.num_dir, np = s.num_point;
     float4 *l_cull = (float4 *)lds;
@@ -144,8 +148,18 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
         else
             l_azk_dir[(which - 1) * image + j] = lane_ < 32 ? e.z : e.w;
     }
+    // headers of the light-space tables behind the MFMA images (whole doubles again: the images are 2*padded64 floats each)
+    double *l_dirgrid = (double *)(l_azk_dir + nd * image), *l_pointgrid = l_dirgrid + nd * kDirGridDoubles;
+    if (grids.enabled)
+    {
+        for (int i = threadIdx.x; i < nd * kDirGridDoubles; i += blockDim.x)
+            l_dirgrid[i] = ((const double *)grids.dir)[i];
+        for (int i = threadIdx.x; i < np * kPointGridDoubles; i += blockDim.x)
+            l_pointgrid[i] = ((const double *)grids.point)[i];
+    }
     __syncthreads();
-    return LdsImage{l_cull, l_cull_dir, l_axy, l_azk, l_azk_dir, padded64, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit};
+    return LdsImage{l_cull, l_cull_dir, l_axy, l_azk, l_azk_dir, padded64, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit,
+                    (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid};
 }
 
 struct Hit
@@ -453,7 +467,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const LdsImage L = stage_lds_image(lds, s, cull, f);
+    const LdsImage L = stage_lds_image(lds, s, cull, f, grids);
     const int n = s.num_spheres, nd = s.num_dir, nl = s.num_dir + s.num_point;
     const int lane = threadIdx.x & 63;
     const unsigned pixels_here = (unsigned)f.local_rows * (unsigned)f.width;
@@ -607,7 +621,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                     const unsigned long long *cell = nullptr;
                     if (grids.enabled)
                     {
-                        const trt_dirgrid *G = grids.dir + li;
+                        const trt_dirgrid *G = L.dirgrid + li; // header in LDS: a global read here would sit in front of the cell's load
                         int far;
                         const int c = trt_dirgrid_cell(G, o.x, o.y, o.z, &far);
                         far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                     const unsigned long long *cell = nullptr;
                     if (grids.enabled)
                     {
-                        const trt_pointgrid *G = grids.point + (li - nd);
+                        const trt_pointgrid *G = L.pointgrid + (li - nd);
                         int far;
                         const int c = trt_pointgrid_cell(G, o.x, o.y, o.z, &far);
                         far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
