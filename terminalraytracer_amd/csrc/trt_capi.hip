@@ -429,6 +429,8 @@ extern "C" int trt_rowset_frame_row(const trt_rowset *r, int local_row)
 extern "C" const char *trt_last_error(void) { return g_error; }
 extern "C" const char *trt_version(void) { return "trt-mi355x 0.1 (gfx950, fp64, contraction off)"; }
 
+static int init_context(trt_context *ctx);
+
 extern "C" int trt_create(int device, trt_context **out)
 {
     if (!out)
@@ -441,6 +443,19 @@ extern "C" int trt_create(int device, trt_context **out)
     HIP_TRY(hipSetDevice(device));
     trt_context *ctx = new trt_context();
     ctx->device = device;
+    const int rc = init_context(ctx);
+    if (rc)
+    { // hand nothing half-built to the caller, keep nothing behind
+        (void)trt_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return TRT_OK;
+}
+
+static int init_context(trt_context *ctx)
+{
+    const int device = ctx->device;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     ctx->compute_units = prop.multiProcessorCount;
@@ -476,7 +491,6 @@ extern "C" int trt_create(int device, trt_context **out)
     (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
-    *out = ctx;
     return TRT_OK;
 }
 
@@ -485,16 +499,22 @@ extern "C" int trt_destroy(trt_context *ctx)
     if (!ctx)
         return TRT_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < kEventRing; i++)
     {
-        (void)hipEventDestroy(ctx->ev_start[i]);
-        (void)hipEventDestroy(ctx->ev_stop[i]);
+        if (ctx->ev_start[i])
+            (void)hipEventDestroy(ctx->ev_start[i]);
+        if (ctx->ev_stop[i])
+            (void)hipEventDestroy(ctx->ev_stop[i]);
     }
     for (int i = 0; i < 16; i++)
-        (void)hipEventDestroy(ctx->ev_chunk[i]);
+        if (ctx->ev_chunk[i])
+            (void)hipEventDestroy(ctx->ev_chunk[i]);
     for (int i = 0; i < 4; i++)
-        (void)hipEventDestroy(ctx->ev_band[i]);
+        if (ctx->ev_band[i])
+            (void)hipEventDestroy(ctx->ev_band[i]);
+    (void)hipGetLastError();
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
     ctx->d_spheres.release();
