@@ -201,6 +201,7 @@ def main():
             "fp64_valu": {"achieved_tflops_reference_opcount": flops / (kavg * 1e-3) / 1e12, "peak_tflops_fma": FP64_PEAK_TFLOPS,
                           "peak_tflops_no_fma": FP64_PEAK_TFLOPS / 2,
                           "note": "reference op count 25*N+17 per trace; the kernel does fewer ops than that (FP32 culling)"},
+            "valu_issue": (measured_traffic()[1] or {}).get("valu"),  # committed PMC summary of this same command
             "kernel_info": r.ctx.kernel_info(),
             # rounds kernel (id 0): one round = one path ray per lane (+ one shadow ray per light for the lanes that hit something)
             "diagnostics": dict(diag, path_lane_utilisation=path_rays / max(1, 64 * diag["wave_loop_trips"]),
