@@ -98,7 +98,9 @@ def main():
     ap.add_argument("--units", type=int, default=0, help="work units of the production kernel: 0 auto, 1 pixels, 2 samples")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
-    ap.add_argument("--depth", type=int, default=2, help="frames in flight per GPU (1 = strictly one frame at a time)")
+    ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = 2 on one GPU, 3 on several)")
+    ap.add_argument("--reserve-cus", type=int, default=-1, help="compute units kept free of render workgroups so that the gather's kernels can "
+                                                               "run beside them (-1 = 0 on one GPU, 8 on several)")
     args = ap.parse_args()
 
     import torch
@@ -110,6 +112,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if args.depth <= 0:
+        args.depth = 2 if world == 1 else 3
+    if args.reserve_cus < 0:
+        args.reserve_cus = 0 if world == 1 else 8
     local = local % max(1, torch.cuda.device_count())  # rehearsals may put several ranks on one GPU
     if world > 1:
         if args.backend == "nccl":
@@ -119,7 +125,7 @@ def main():
     torch.cuda.set_device(local)
 
     scene = build_scene()
-    r = HipShardRenderer(scene, W, H, rank, world, local, BOUNCES, SPP, depth=args.depth)
+    r = HipShardRenderer(scene, W, H, rank, world, local, BOUNCES, SPP, depth=args.depth, reserve_cus=args.reserve_cus)
     r.for_each_context(lambda c: (c.set_kernel(args.kernel), c.set_work_units(args.units)))
 
     # untimed: per-frame ray counts of this rank's rows (counting variant of the kernel)
@@ -187,7 +193,7 @@ def main():
                                    "1 directional + 1 point light, 8 bounces, 10 rays/pixel, 256^2 procedural cubemap, "
                                    "off-screen f64 framebuffer", "sharding": f"{world} x interleaved 8-row tiles, 1 gather/frame",
                        "kernel": {0: "persistent waves, synchronous rounds", 1: "reference-order", 2: "persistent state machine"}[args.kernel],
-                       "frames_in_flight": args.depth},
+                       "frames_in_flight": args.depth, "reserved_cus": args.reserve_cus},
             "rays_per_frame": {"path": path_total, "shadow": shadow_total},
             "all_rays_per_s": (path_total + shadow_total) * args.steps / seconds,
             "kernel_ms_avg": kavg,

@@ -85,6 +85,15 @@ int trt_destroy(trt_context *ctx);
  * PyTorch callers pass torch.cuda.current_stream().cuda_stream. */
 int trt_set_stream(trt_context *ctx, void *hip_stream);
 
+/* Keep `reserved` compute units free of this context's kernels: its own stream is re-created with a CU mask and the
+ * persistent kernel is sized for the remaining CUs.  The frame producer's workgroups are persistent and hold every
+ * wave slot they are given until the frame ends; a collective that has to run beside them (the RCCL gather of the
+ * previous frame in a multi-GPU run) would otherwise wait for a frame to drain.  Applies to the context's own stream
+ * (not to one handed in with trt_set_stream); 0 removes the mask.  trt_get_stream returns the stream in use, e.g. to
+ * wrap it for event synchronisation (torch.cuda.ExternalStream). */
+int trt_reserve_cus(trt_context *ctx, int reserved);
+int trt_get_stream(trt_context *ctx, void **hip_stream);
+
 /* Upload everything of *scene except the camera: spheres, ground, lights, skybox texels.
  * (Scene layout TRT.c:196-208.)  Synchronous; call once per scene, not per frame. */
 int trt_set_scene(trt_context *ctx, const Scene *scene);

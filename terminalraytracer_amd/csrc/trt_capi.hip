@@ -96,6 +96,7 @@ struct trt_context
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int compute_units = 0;
+    int reserved_cus = 0; // CUs the context's own stream may not use (trt_reserve_cus)
     int lds_limit = 0;
 
     bool have_scene = false;
@@ -552,6 +553,42 @@ extern "C" int trt_set_stream(trt_context *ctx, void *hip_stream)
     return TRT_OK;
 }
 
+extern "C" int trt_reserve_cus(trt_context *ctx, int reserved)
+{
+    if (!ctx || reserved < 0)
+        return fail(TRT_ERR_ARGUMENT, "bad argument");
+    if (reserved > ctx->compute_units / 2)
+        return fail(TRT_ERR_ARGUMENT, "%d of %d compute units", reserved, ctx->compute_units);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const bool was_own = ctx->stream == ctx->own_stream;
+    hipStream_t fresh = nullptr;
+    if (reserved == 0)
+        HIP_TRY(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    else
+    { // one bit per CU; the driver deals consecutive bits round the XCDs, so dropping the top bits thins every XCD alike
+        std::vector<uint32_t> mask((size_t)(ctx->compute_units + 31) / 32, 0u);
+        for (int cu = 0; cu < ctx->compute_units - reserved; cu++)
+            mask[(size_t)cu / 32] |= 1u << (cu % 32);
+        HIP_TRY(hipExtStreamCreateWithCUMask(&fresh, (uint32_t)mask.size(), mask.data()));
+    }
+    if (ctx->own_stream)
+        (void)hipStreamDestroy(ctx->own_stream);
+    ctx->own_stream = fresh;
+    if (was_own)
+        ctx->stream = fresh;
+    ctx->reserved_cus = reserved;
+    return TRT_OK;
+}
+
+extern "C" int trt_get_stream(trt_context *ctx, void **hip_stream)
+{
+    if (!ctx || !hip_stream)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    *hip_stream = (void *)ctx->stream;
+    return TRT_OK;
+}
+
 extern "C" int trt_set_scene(trt_context *ctx, const Scene *scene)
 {
     if (!ctx || !scene)
@@ -752,7 +789,7 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
             f.samples = ctx->d_samples.ptr;
             f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
         }
-        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units, blocks_per_cu, units);
+        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0), blocks_per_cu, units);
         const size_t plds = trt::persistent_lds_bytes(ctx->scene, rays_per_pixel);
         const dim3 grid(pl.grid), block(pl.block);
         const bool count = ctx->counters_enabled;

@@ -82,7 +82,10 @@ class HipShardRenderer:
     """Product path: this rank's row tiles rendered by libtrt_hip.so into a shard tensor, frames PIPELINED.
 
     `depth` renderer contexts, each with its own HIP stream, shard buffer and gather buffers, take the frames
-    round-robin.  A persistent-wave frame ends with a tail in which most CUs are already idle; with two frames
+    round-robin.  For world > 1 use depth 3 and reserve a few compute units (`reserve_cus`): the persistent workgroups of
+    the next frame otherwise keep the gather's kernels (and this frame's reduction) off the machine until that frame has
+    drained, and a frame costs render + gather instead of max(render, gather) (tools/gather_sim.py: 0.57 -> 0.30 ms per
+    1/8 shard with a 0.2 ms stand-in for the gather).  A persistent-wave frame ends with a tail in which most CUs are already idle; with two frames
     in flight the next frame's workgroups fill those CUs (measured on one MI355X at 1080p: 3.33 -> 2.98 ms per
     whole frame, 0.64 -> 0.38 ms per 1/8 shard), and the gather of frame f overlaps the rendering of f+1.
     Ordering is by events: a slot renders only after the assembly of its previous frame was enqueued, and the
@@ -90,9 +93,12 @@ class HipShardRenderer:
     is overwritten `depth` calls later."""
 
     def __init__(self, scene_data, width, height, rank, world, local_device, bounce_limit, rays_per_pixel,
-                 tile_rows=8, depth=2, rgb8=False):
+                 tile_rows=8, depth=2, rgb8=False, reserve_cus=0):
         """rgb8=True: every rank quantises its shard on the device (trt_quantize_device) and the 3-byte pixels are
-        gathered instead of the doubles -- all a terminal emitter needs, and bit-exact for it."""
+        gathered instead of the doubles -- all a terminal emitter needs, and bit-exact for it.
+        reserve_cus > 0: the renderers' streams leave that many compute units alone (trt_reserve_cus).  The frame
+        producer's workgroups are persistent and fill every wave slot; the gather's own kernels would otherwise have to
+        wait for a frame to drain before they get on the machine."""
         torch.cuda.set_device(local_device)
         self.bounce_limit, self.rays_per_pixel = bounce_limit, rays_per_pixel
         self.rgb8 = rgb8
@@ -100,13 +106,21 @@ class HipShardRenderer:
         for _ in range(max(1, depth)):
             ctx = hip.Context(local_device)
             ctx.set_scene(scene_data)
-            stream = torch.cuda.Stream(device=local_device)
-            ctx.set_stream(stream.cuda_stream)
+            if reserve_cus > 0:
+                ctx.reserve_cus(reserve_cus)  # the library's own stream, with a CU mask; torch only needs its handle
+                stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=torch.device(f"cuda:{local_device}"))
+            else:
+                stream = torch.cuda.Stream(device=local_device)
+                ctx.set_stream(stream.cuda_stream)
             frame = ShardedFrame(width, height, rank, world, f"cuda:{local_device}", tile_rows,
                                  dtype=torch.uint8 if rgb8 else torch.float64)
             self.slots.append({"ctx": ctx, "stream": stream, "frame": frame,
                                "pixels": torch.zeros((frame.max_rows, width, 3), dtype=torch.float64, device=f"cuda:{local_device}") if rgb8 else frame.shard,
                                "rendered": torch.cuda.Event(), "consumed": torch.cuda.Event()})
+        self.external_streams = reserve_cus > 0
+        # CU-masked streams are "blocking" streams: they order themselves against the NULL stream.  With them, the
+        # assembly (wait, gather, index_select) runs on a stream of its own so that nothing in the loop touches stream 0.
+        self.main = torch.cuda.Stream(device=local_device) if self.external_streams else None
         self.calls = 0
         self.ctx = self.slots[0]["ctx"]          # for counters / kernel selection helpers
         self.sharded = self.slots[0]["frame"]
@@ -116,8 +130,11 @@ class HipShardRenderer:
             fn(slot["ctx"])
 
     def render(self, camera):
+        """Enqueue one frame; returns the assembled frame tensor on the root (None elsewhere).  The tensor is valid on the
+        current torch stream -- or, when compute units are reserved, on `self.main` (synchronise the device, or make your
+        stream wait on `self.main`, before reading it)."""
         slot = self.slots[self.calls % len(self.slots)]
-        main = torch.cuda.current_stream()
+        main = self.main if self.main is not None else torch.cuda.current_stream()
         if self.calls >= len(self.slots):
             slot["stream"].wait_event(slot["consumed"])  # the previous frame of this slot has been assembled
         self.calls += 1
@@ -127,9 +144,10 @@ class HipShardRenderer:
         if self.rgb8:
             slot["ctx"].quantize_device(px.data_ptr(), s.local_rows * s.width, s.shard.data_ptr())
         slot["rendered"].record(slot["stream"])
-        main.wait_event(slot["rendered"])
-        frame = s.assemble()
-        slot["consumed"].record(main)
+        with torch.cuda.stream(main):
+            main.wait_event(slot["rendered"])
+            frame = s.assemble()
+            slot["consumed"].record(main)
         return frame
 
     def kernel_times(self, launches):
@@ -143,5 +161,6 @@ class HipShardRenderer:
     def close(self):
         torch.cuda.synchronize()
         for slot in self.slots:
-            slot["ctx"].set_stream(None)
+            if not self.external_streams:
+                slot["ctx"].set_stream(None)
             slot["ctx"].close()

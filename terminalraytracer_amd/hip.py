@@ -68,6 +68,8 @@ SYMBOLS = {
     "trt_set_kernel": (_I, [_VP, _I]),
     "trt_set_work_units": (_I, [_VP, _I]),
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
+    "trt_reserve_cus": (_I, [_VP, _I]),
+    "trt_get_stream": (_I, [_VP, C.POINTER(C.c_void_p)]),
     "trt_selftest_unit": (_I, [_VP, _VP, C.c_size_t, _VP, _VP]),
     "trt_read_light_grid": (C.c_long, [_VP, _I, _I, _VP, C.c_size_t]),
     "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
@@ -150,6 +152,16 @@ class Context:
     def set_work_units(self, units):
         """0 automatic, 1 pixels, 2 samples (trt_set_work_units)"""
         _check(lib().trt_set_work_units(self._h, units))
+
+    def reserve_cus(self, reserved):
+        """keep `reserved` compute units free of this context's kernels (trt_reserve_cus)"""
+        _check(lib().trt_reserve_cus(self._h, reserved))
+
+    def stream_ptr(self):
+        """the HIP stream the context launches on, as an integer (trt_get_stream)"""
+        p = C.c_void_p()
+        _check(lib().trt_get_stream(self._h, C.byref(p)))
+        return p.value or 0
 
     def set_light_grids(self, directional_cells, point_cells):
         """cells per side of the light-space candidate tables; 0, 0 = off (trt_set_light_grids)"""
