@@ -106,10 +106,17 @@ class HipShardRenderer:
         for _ in range(max(1, depth)):
             ctx = hip.Context(local_device)
             ctx.set_scene(scene_data)
+            stream = None
             if reserve_cus > 0:
-                ctx.reserve_cus(reserve_cus)  # the library's own stream, with a CU mask; torch only needs its handle
-                stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=torch.device(f"cuda:{local_device}"))
-            else:
+                try:
+                    ctx.reserve_cus(reserve_cus)  # the library's own stream, with a CU mask; torch only needs its handle
+                    stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=torch.device(f"cuda:{local_device}"))
+                except Exception as e:  # an optimisation only: render on an ordinary stream if the mask cannot be had
+                    import sys
+                    print(f"HipShardRenderer: no compute units reserved ({type(e).__name__}: {e})", file=sys.stderr)
+                    ctx.reserve_cus(0)
+                    reserve_cus = 0
+            if stream is None:
                 stream = torch.cuda.Stream(device=local_device)
                 ctx.set_stream(stream.cuda_stream)
             frame = ShardedFrame(width, height, rank, world, f"cuda:{local_device}", tile_rows,
