@@ -222,6 +222,26 @@ def test_sharded_renderer_world_of_one(ctx):
         r.close()
 
 
+def test_sharded_renderer_with_reserved_compute_units_and_three_frames_in_flight(ctx):
+    """The multi-GPU defaults of bench.py on one rank: CU-masked render streams (trt_reserve_cus), three slots, the assembly
+    on a stream of its own.  Every frame of a short orbit must come out as the reference's, in order."""
+    import torch
+    from terminalraytracer_amd.distributed import HipShardRenderer
+    case = next(c for c in SMALL if c["name"] == "synth64_128x72_b8")
+    scene = T.golden_scene(case)
+    r = HipShardRenderer(scene, 128, 72, 0, 1, 0, 8, 10, depth=3, reserve_cus=8)
+    try:
+        assert r.external_streams and r.main is not None
+        frames = []
+        for _ in range(7):  # every slot reused at least twice
+            frames.append(r.render(scene.camera))
+            torch.cuda.synchronize()
+            assert T.fnv(frames[-1].cpu().numpy()) == case["fb_fnv"]
+        assert r.ctx.kernel_info()["compute_units"] >= 8
+    finally:
+        r.close()
+
+
 def test_c_demo_driver_runs_the_reference_frame_loop(tmp_path):
     """examples/trt_demo: host C (scene literals, camera orbit, PPM loader, emitter) + GPU project_scene."""
     import os
