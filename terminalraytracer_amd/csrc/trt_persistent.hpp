@@ -85,6 +85,7 @@ constexpr unsigned kQueueChunkPixels = 64;   // work units fetched from the glob
 #define TRT_QUEUE_CHUNK 256
 #endif
 constexpr unsigned kQueueChunkSamples = TRT_QUEUE_CHUNK;
+static_assert(kQueueChunkSamples >= 64, "a chunk must hold the 64 units the lanes of a wave can ask for in one round");
 #ifndef TRT_CULL_GROUP
 #define TRT_CULL_GROUP 8
 #endif
