@@ -19,14 +19,15 @@
 //
 // Because all lanes of a wave are in the same stage, there is no per-lane state machine and no merging of
 // modes; the code of each stage is straight-line with exec masking only for "hit" vs "sky".  The price is
-// that lanes whose path ray reached the sky idle through the shadow stages of that round (the sphere sweep is
-// wave-uniform work, so it costs the same whether 36 or 64 lanes take part).
+// that lanes whose path ray reached the sky idle through the shadow stages of that round.
 //
-// The trace itself is the two-phase search described in trt_filter.h / trt_persistent.hpp: a wave-uniform FP32
-// sweep over a culling table in LDS (broadcast ds_read_b128, 11 VALU per sphere, verdict in a sign bit)
-// followed by per-lane EXACT FP64 tests of the few candidates in ascending index order.  FP64, contraction
-// off: results are bit-identical to the reference.  The mean over a pixel's samples is formed by
-// reduce_samples_kernel in the reference's order (TRT.c:1063-1065).
+// The trace itself is a two-phase search.  Phase 1 proposes candidate spheres: for a PATH ray a wave-uniform FP32
+// sweep over a culling table in LDS (trt_filter.h: broadcast ds_read_b128, 9 VALU per sphere, verdict in a sign
+// bit); for a SHADOW ray one look-up in the light's table in light space (trt_lightgrid.h: the rays towards one
+// light are a two-parameter family), with the sweep as the fall-back for origins outside the table's range.
+// Phase 2 is per lane: the EXACT FP64 test of the few candidates in ascending index order.  Neither filter ever
+// decides a hit.  FP64, contraction off: results are bit-identical to the reference.  The mean over a pixel's
+// samples is formed by reduce_samples_kernel in the reference's order (TRT.c:1063-1065).
 #pragma once
 
 #include "trt_device.hpp"
