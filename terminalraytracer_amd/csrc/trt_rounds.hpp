@@ -404,26 +404,24 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
                     const double cc = dot(oc, oc) - L.r2[i];
                     const double disc = b * b - 4.0 * a * cc;
                     if (!(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
-                    {
+                    { // no further branches: selects keep `best` in place (nested ifs cost five register copies per level)
                         const double t0 = (-b - sqrt_exact(disc)) / (2.0 * a);
-                        if (t0 > 0.0)
+                        const bool hit = t0 > 0.0;
+                        if (ANY_HIT)
+                        { // "anything in the way?" (TRT.c:908): the first hit answers it; its position is never used
+                            best.i = hit ? i : best.i;
+                            cand = hit ? 0ull : cand;
+                        }
+                        else
                         {
-                            if (ANY_HIT)
-                            { // "anything in the way?" (TRT.c:908): the first hit answers it; its position is never used
-                                best.i = i;
-                                cand = 0;
-                            }
-                            else
-                            {
-                                const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
-                                const double d2 = dist2(o, p);
-                                if (d2 < best.d2)
-                                {
-                                    best.d2 = d2;
-                                    best.p = p;
-                                    best.i = i;
-                                }
-                            }
+                            const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
+                            const double d2 = dist2(o, p);
+                            const bool closer = hit && d2 < best.d2;
+                            best.d2 = closer ? d2 : best.d2;
+                            best.p.x = closer ? p.x : best.p.x;
+                            best.p.y = closer ? p.y : best.p.y;
+                            best.p.z = closer ? p.z : best.p.z;
+                            best.i = closer ? i : best.i;
                         }
                     }
                 }
