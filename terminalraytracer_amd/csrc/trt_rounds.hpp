@@ -389,41 +389,36 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         }
         // phase 2: exact FP64 tests of this lane's candidates, ascending index (first index wins ties, TRT.c:816)
         while (__any(cand != 0))
-        {
+        { // predicated rather than branched: a lane without a candidate tests sphere 0 and discards the result
             phase2_rounds++;
-            if (cand != 0)
-            {
-                const int lead = __builtin_clzll(cand);
-                const int i = base + lead;
-                cand &= ~(0x8000000000000000ull >> lead);
-                if (i < n)
+            const int lead = __builtin_clzll(cand | 1ull);
+            const bool valid = cand != 0 && base + lead < n;
+            const int i = valid ? base + lead : 0;
+            cand &= ~(0x8000000000000000ull >> lead);
+            const d3 c = d3{L.cx[i], L.cy[i], L.cz[i]};
+            const d3 oc = sub(o, c);
+            const double b = 2.0 * dot(oc, d);
+            const double cc = dot(oc, oc) - L.r2[i];
+            const double disc = b * b - 4.0 * a * cc;
+            if (valid && !(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
+            { // no further branches: selects keep `best` in place (nested ifs cost five register copies per level)
+                const double t0 = (-b - sqrt_exact(disc)) / (2.0 * a);
+                const bool hit = t0 > 0.0;
+                if (ANY_HIT)
+                { // "anything in the way?" (TRT.c:908): the first hit answers it; its position is never used
+                    best.i = hit ? i : best.i;
+                    cand = hit ? 0ull : cand;
+                }
+                else
                 {
-                    const d3 c = d3{L.cx[i], L.cy[i], L.cz[i]};
-                    const d3 oc = sub(o, c);
-                    const double b = 2.0 * dot(oc, d);
-                    const double cc = dot(oc, oc) - L.r2[i];
-                    const double disc = b * b - 4.0 * a * cc;
-                    if (!(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
-                    { // no further branches: selects keep `best` in place (nested ifs cost five register copies per level)
-                        const double t0 = (-b - sqrt_exact(disc)) / (2.0 * a);
-                        const bool hit = t0 > 0.0;
-                        if (ANY_HIT)
-                        { // "anything in the way?" (TRT.c:908): the first hit answers it; its position is never used
-                            best.i = hit ? i : best.i;
-                            cand = hit ? 0ull : cand;
-                        }
-                        else
-                        {
-                            const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
-                            const double d2 = dist2(o, p);
-                            const bool closer = hit && d2 < best.d2;
-                            best.d2 = closer ? d2 : best.d2;
-                            best.p.x = closer ? p.x : best.p.x;
-                            best.p.y = closer ? p.y : best.p.y;
-                            best.p.z = closer ? p.z : best.p.z;
-                            best.i = closer ? i : best.i;
-                        }
-                    }
+                    const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
+                    const double d2 = dist2(o, p);
+                    const bool closer = hit && d2 < best.d2;
+                    best.d2 = closer ? d2 : best.d2;
+                    best.p.x = closer ? p.x : best.p.x;
+                    best.p.y = closer ? p.y : best.p.y;
+                    best.p.z = closer ? p.z : best.p.z;
+                    best.i = closer ? i : best.i;
                 }
             }
         }
