@@ -107,6 +107,12 @@ inline PersistentLaunch persistent_launch_shape(int compute_units, int blocks_pe
 //            dir lights: unit to-light(3) colour(3) | point lights: pos(3) colour(3) intensity | byte/255.0 [256] |
 //            camera: basis x,y,z (9) eye (3) -screen_distance (1) | jitter x[spp] y[spp]
 constexpr int kLdsCameraDoubles = 13;
+// TRT_SWEEP_MFMA == 2 (rounds kernel, experiment): per wave, the rays' filter vectors (64 x 9 floats) and the exchange
+// buffer of the verdict words (64 lanes x 4 x 8 bytes) behind the LDS image
+#ifndef TRT_SWEEP_MFMA
+#define TRT_SWEEP_MFMA 0
+#endif
+constexpr int kMfma16RayFloats = 9, kMfma16WaveFloats = 64 * kMfma16RayFloats + 64 * 8;
 constexpr int kDirGridDoubles = 10, kPointGridDoubles = 6; // sizeof(trt_dirgrid) / 8, sizeof(trt_pointgrid) / 8 (asserted in trt_rounds.hpp)
 inline size_t persistent_lds_bytes(const SceneView &s, int spp)
 {
@@ -116,7 +122,8 @@ inline size_t persistent_lds_bytes(const SceneView &s, int spp)
                              (TRT_SWEEP_LDS ? padded * 2 : 0) /* culling table first: 4 floats per sphere, 16-B aligned */ +
                              (size_t)s.num_dir * padded * 2 /* one fixed-direction table per directional light (rounds kernel) */ +
                              (2 + (size_t)s.num_dir) * (((size_t)s.num_spheres + 63) / 64 * 64) /* MFMA A-operand images, 2*padded64 floats each (rounds kernel) */ +
-                             (size_t)s.num_dir * kDirGridDoubles + (size_t)s.num_point * kPointGridDoubles /* light-table headers (rounds kernel) */);
+                             (size_t)s.num_dir * kDirGridDoubles + (size_t)s.num_point * kPointGridDoubles /* light-table headers (rounds kernel) */ +
+                             (TRT_SWEEP_MFMA == 2 ? (size_t)(kPersistentBlock / 64) * kMfma16WaveFloats / 2 : 0));
 }
 
 struct CullView

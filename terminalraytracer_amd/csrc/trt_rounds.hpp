@@ -44,6 +44,8 @@ namespace trt
 //   MFMA sweep, 166 VGPRs, 3 waves/SIMD                         3.34 ms   (6 % faster than the VALU sweep at 3 waves)
 //   MFMA sweep forced to 128 VGPRs (140 B/lane of scratch)      3.75 ms
 // The 32 accumulator registers of a 32x32 tile pair cost the fourth wave, which is worth more than the offload.
+// 2 = 16x16x4 tiles for the path rays only (mfma16_sweep below; shadow rays keep their tables): exact as well, measured
+//   VALU sweep, 124 VGPRs 2.24 ms | 16x16x4 MFMA, 131 VGPRs, 3 waves/SIMD 2.51 ms | forced to 128 VGPRs 2.38 ms.
 #ifndef TRT_SWEEP_MFMA
 #define TRT_SWEEP_MFMA 0
 #endif
@@ -78,6 +80,7 @@ struct LdsImage
     const double *jit;   // jitter x[spp], y[spp]
     const trt_dirgrid *dirgrid;     // headers of the light-space tables (trt_lightgrid.h), per directional light
     const trt_pointgrid *pointgrid; // per point light
+    float *mfma16_wave;             // TRT_SWEEP_MFMA == 2: this wave's staging / exchange area
 };
 
 // same layout and size as trt_persistent.hpp (persistent_lds_bytes)
@@ -134,7 +137,7 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
     // MFMA operand images behind the fixed-direction tables: per 32-sphere block 64 floats (lane l: k = l/32 of sphere l%32)
     const int padded64 = (n + 63) / 64 * 64, image = 2 * padded64;
     float *l_axy = (float *)(l_cull_dir + nd * cull.padded), *l_azk = l_axy + image, *l_azk_dir = l_azk + image;
-    for (int i = threadIdx.x; i < (TRT_SWEEP_MFMA ? (1 + nd) * image : 0); i += blockDim.x)
+    for (int i = threadIdx.x; i < (TRT_SWEEP_MFMA == 1 ? (1 + nd) * image : 0); i += blockDim.x)
     {
         const int which = i / image, j = i - which * image; // which: 0 generic table, 1 + li fixed direction of light li
         const int lane_ = j & 63, sphere = (j >> 6) * 32 + (lane_ & 31);
@@ -160,7 +163,8 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
     }
     __syncthreads();
     return LdsImage{l_cull, l_cull_dir, l_axy, l_azk, l_azk_dir, padded64, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit,
-                    (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid};
+                    (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid,
+                    (float *)(l_pointgrid + np * kPointGridDoubles) + (threadIdx.x >> 6) * kMfma16WaveFloats};
 }
 
 struct Hit
@@ -249,6 +253,65 @@ TRT_DEV void sweep64_mfma(const float *a_xy, const float *a_zk, int lane, const 
     half1 = __builtin_bit_cast(unsigned, word[1]);
 }
 
+#if TRT_SWEEP_MFMA == 2
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// Phase 1 of a PATH ray on the matrix cores, 16x16x4 tiles (experiment).  v_mfma_f32_16x16x4_f32 is the FMA
+// chain over k = 0..3 starting from C (tools/mfma16_probe: bit-identical), i.e. the order of trt_filter_sign_mfma.
+// Rows = spheres (A straight from the {Cx,Cy,Cz,kk} table: lane l reads component l/16 of sphere l%16 of the tile),
+// columns = rays (B from the rays' vectors staged in LDS once per trace: lane l reads component l/16 of ray 16t + l%16),
+// D: lane l, register v = sphere 4*(l/16) + v of the tile, ray 16t + l%16.  Each lane packs the sign bits it holds into
+// their final positions of the ray's candidate word; the ray's own lane ORs the four partial words via LDS.
+TRT_DEV void mfma16_stage_ray(float *wave, int lane, const trt_ray_filter &f)
+{
+    float *r = wave + lane * kMfma16RayFloats;
+    r[0] = f.wx, r[1] = f.wy, r[2] = f.wz, r[3] = -1.0f;
+    r[4] = f.dx, r[5] = f.dy, r[6] = f.dz, r[7] = 0.0f;
+    r[8] = f.neg_thr;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// bit 63-j set = sphere j of the chunk is REJECTED for this lane's ray
+TRT_DEV unsigned long long mfma16_sweep(const float4 *table, float *wave, int lane)
+{
+    const int q = lane >> 4, c = lane & 15;
+    float a[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+        a[s] = ((const float *)table)[(16 * s + c) * 4 + q];
+    unsigned long long *xch = (unsigned long long *)(wave + 64 * kMfma16RayFloats);
+    const unsigned shift = 12u - 4u * (unsigned)q;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+    {
+        const float *ray = wave + (16 * t + c) * kMfma16RayFloats;
+        const float bw = ray[q], bd = ray[4 + q], thr = ray[8];
+        unsigned word[2] = {0u, 0u};
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+        {
+            f4v cw = {thr, thr, thr, thr}, cd = {0.0f, 0.0f, 0.0f, 0.0f};
+            cw = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw, cw, 0, 0, 0);
+            cd = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bd, cd, 0, 0, 0);
+            unsigned w = word[s >> 1];
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+            {
+                const float m = __builtin_fmaf(cd[v], cd[v], cw[v]);
+                w = __builtin_amdgcn_alignbit(w, __builtin_bit_cast(unsigned, m), 31);
+            }
+            word[s >> 1] = (s & 1) ? w : w << 12;
+        }
+        xch[lane * 4 + t] = ((unsigned long long)(word[0] << shift) << 32) | (word[1] << shift);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int own = lane >> 4;
+    const unsigned long long rejected = xch[c * 4 + own] | xch[(c + 16) * 4 + own] | xch[(c + 32) * 4 + own] | xch[(c + 48) * 4 + own];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the next chunk overwrites the exchange buffer
+    return rejected;
+}
+#endif
+
 // Closest hit of TRT.c:793-856 for the lanes with `active`.  ANY_HIT: the caller only asks whether anything
 // is hit (directional-light shadow ray, TRT.c:908), so a lane stops at its first hit and the ground is skipped
 // once a sphere was found.  `a_zk_fixed` != nullptr: all rays share the direction that table was built for.
@@ -282,10 +345,15 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     best.i = -1;
     const double a = dot(d, d);
     trt_ray_filter flt;
-    if (TRT_SWEEP_MFMA || !use_masks)
+    if (TRT_SWEEP_MFMA == 1 || !use_masks)
         trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
+#if TRT_SWEEP_MFMA == 2
+    const bool matrix_sweep = !use_masks && !(ANY_HIT && fixed); // the general sweep; a fixed-direction fall-back stays on the VALU
+    if (matrix_sweep)
+        mfma16_stage_ray(L.mfma16_wave, lane, flt);
+#endif
 
-#if TRT_SWEEP_MFMA
+#if TRT_SWEEP_MFMA == 1
     for (int base = 0; base < L.padded64; base += 64)
     {
         // phase 1 on the matrix cores (all 64 lanes take part: the tiles hold every lane's column)
@@ -356,6 +424,17 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         {
         TRT_TRACE_STAMP(0);
         unsigned word[2];
+#if TRT_SWEEP_MFMA == 2
+        if (matrix_sweep)
+        {
+            const unsigned long long rejected = mfma16_sweep(L.cull + base, L.mfma16_wave, lane);
+            word[0] = ~(unsigned)(rejected >> 32), word[1] = ~(unsigned)rejected;
+            const int c0 = chunk < 32 ? chunk : 32, c1 = chunk - c0; // entries past the table's end are not spheres
+            word[0] &= c0 == 32 ? ~0u : ~(0xffffffffu >> c0);
+            word[1] &= c1 == 32 ? ~0u : (c1 == 0 ? 0u : ~(0xffffffffu >> c1));
+        }
+        else
+#endif
 #pragma unroll
         for (int h = 0; h < 2; h++)
         {
