@@ -103,7 +103,7 @@ struct trt_context
     trt::SceneView scene{};
     trt::CullView cull{};
     int persistent_blocks_per_cu = 0; // occupancy of the production kernel for the current scene's LDS image
-    DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb, d_axes, d_samples;
+    DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb, d_axes, d_samples, d_samples_alt;
     DeviceBuffer<float> d_cull;
     // light-space candidate masks (trt_lightgrid.h) and the host copy of the primitives they were built from
     DeviceBuffer<unsigned long long> d_dir_masks, d_point_masks;
@@ -131,8 +131,10 @@ struct trt_context
     int rounds_blocks_per_cu = 0;
     size_t occupancy_for_lds = (size_t)-1;
     hipEvent_t ev_chunk[16]; // hand-over of framebuffer chunks to the host copy threads (trt_render_host)
-    hipEvent_t ev_band[4];   // a band of rows is rendered: its copy-out may start (trt_render_host)
+    hipEvent_t ev_band[8];   // a band of rows is rendered: its copy-out may start (trt_render_host)
     hipStream_t copy_stream = nullptr;
+    hipStream_t alt_stream = nullptr; // second render stream of trt_render_host: odd bands (their tails overlap the next band)
+    hipEvent_t ev_fork = nullptr;
     int units = 0;  // work units of the production kernel: 0 automatic, 1 pixels, 2 samples
     bool counters_enabled = false;
     unsigned long long last_trips = 0, last_phase2 = 0; // diagnostics of the counting kernel variant
@@ -476,9 +478,11 @@ static int init_context(trt_context *ctx)
     }
     for (int i = 0; i < 16; i++)
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_band[i], hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIP_TRY(ctx->d_counters.reserve(kCounterSlots));
     HIP_TRY(ctx->d_queue.reserve(64));
     HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long)));
@@ -512,18 +516,23 @@ extern "C" int trt_destroy(trt_context *ctx)
     for (int i = 0; i < 16; i++)
         if (ctx->ev_chunk[i])
             (void)hipEventDestroy(ctx->ev_chunk[i]);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
         if (ctx->ev_band[i])
             (void)hipEventDestroy(ctx->ev_band[i]);
     (void)hipGetLastError();
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->alt_stream)
+        (void)hipStreamDestroy(ctx->alt_stream);
+    if (ctx->ev_fork)
+        (void)hipEventDestroy(ctx->ev_fork);
     ctx->d_spheres.release();
     ctx->d_dir.release();
     ctx->d_point.release();
     ctx->d_jitter.release();
     ctx->d_axes.release();
     ctx->d_samples.release();
+    ctx->d_samples_alt.release();
     ctx->d_fb.release();
     ctx->d_cull.release();
     ctx->d_dir_masks.release();
@@ -712,8 +721,19 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
     return TRT_OK;
 }
 
+// `lane_set` 0: the context's stream, queue word 0, d_samples; 1: the alternate stream, its own queue word and scratch
+// (trt_render_host renders odd bands there).
+static int render_device_on(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit, int rays_per_pixel,
+                            void *d_pixels, size_t capacity_bytes, int lane_set);
+
 extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit,
                                  int rays_per_pixel, void *d_pixels, size_t capacity_bytes)
+{
+    return render_device_on(ctx, camera, rows, bounce_limit, rays_per_pixel, d_pixels, capacity_bytes, 0);
+}
+
+static int render_device_on(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit, int rays_per_pixel,
+                            void *d_pixels, size_t capacity_bytes, int lane_set)
 {
     if (!ctx || !camera || !d_pixels)
         return fail(TRT_ERR_ARGUMENT, "NULL argument");
@@ -732,6 +752,8 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
     if ((unsigned long long)local_rows * rows->width >= 0x7fffffffull)
         return fail(TRT_ERR_ARGUMENT, "%d x %d pixels exceed the 2^31 pixel index range", local_rows, rows->width);
     HIP_TRY(hipSetDevice(ctx->device));
+    const hipStream_t stream = lane_set ? ctx->alt_stream : ctx->stream;
+    DeviceBuffer<double> &scratch = lane_set ? ctx->d_samples_alt : ctx->d_samples;
     int rc = prepare_jitter(ctx, camera, rows->width, rows->height, rays_per_pixel);
     if (rc)
         return rc;
@@ -748,7 +770,7 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
     f.width_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rows->width - 1) / (unsigned)rows->width, 0xffffffffull);
     f.out = (double *)d_pixels;
     f.counters = ctx->counters_enabled ? ctx->d_counters.ptr : nullptr;
-    f.queue = ctx->d_queue.ptr;
+    f.queue = ctx->d_queue.ptr + 16 * lane_set; // a cache line apart
     f.width = rows->width;
     f.height = rows->height;
     f.tile_rows = rows->tile_rows;
@@ -761,19 +783,19 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
     const long pixels = (long)local_rows * rows->width;
     const size_t lds = scene_lds_bytes(ctx->scene);
     if (ctx->counters_enabled)
-        HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long), stream));
     const int slot = (int)(ctx->launches % kEventRing);
     if (ctx->kernel == 1)
     {
         const int block = 256;
         const unsigned grid = (unsigned)((pixels + block - 1) / block);
-        HIP_TRY(hipEventRecord(ctx->ev_start[slot], ctx->stream));
-        hipLaunchKernelGGL(trt::render_simple_kernel, dim3(grid), dim3(block), lds, ctx->stream, ctx->scene, f);
-        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+        hipLaunchKernelGGL(trt::render_simple_kernel, dim3(grid), dim3(block), lds, stream, ctx->scene, f);
+        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
     }
     else
     {
-        HIP_TRY(hipMemsetAsync(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_queue.ptr + 16 * lane_set, 0, 16 * sizeof(unsigned int), stream));
         // production (kernel 0): synchronous rounds over sample units; pixel units on request go to the state machine
         const bool rounds = ctx->kernel == 0 && ctx->units != 1;
         const bool sample_units = rounds || ctx->units != 1;
@@ -783,42 +805,42 @@ extern "C" int trt_render_device(trt_context *ctx, const Camera *camera, const t
             return fail(TRT_ERR_ARGUMENT, "%ld work units exceed the 2^31 index range", units);
         if (sample_units)
         {
-            if (ctx->d_samples.capacity < (size_t)units * 3)
-                HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still use the old scratch
-            HIP_TRY(ctx->d_samples.reserve((size_t)units * 3));
-            f.samples = ctx->d_samples.ptr;
+            if (scratch.capacity < (size_t)units * 3)
+                HIP_TRY(hipStreamSynchronize(stream)); // a frame in flight may still use the old scratch
+            HIP_TRY(scratch.reserve((size_t)units * 3));
+            f.samples = scratch.ptr;
             f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
         }
         const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0), blocks_per_cu, units);
         const size_t plds = trt::persistent_lds_bytes(ctx->scene, rays_per_pixel);
         const dim3 grid(pl.grid), block(pl.block);
         const bool count = ctx->counters_enabled;
-        HIP_TRY(hipEventRecord(ctx->ev_start[slot], ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
         if (rounds)
         {
             if (count)
-                hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f, ctx->grids);
+                hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
             else
-                hipLaunchKernelGGL((trt::render_rounds_kernel<false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f, ctx->grids);
+                hipLaunchKernelGGL((trt::render_rounds_kernel<false>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         }
         else if (sample_units)
         {
             if (count)
-                hipLaunchKernelGGL((trt::render_persistent_kernel<true, true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+                hipLaunchKernelGGL((trt::render_persistent_kernel<true, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f);
             else
-                hipLaunchKernelGGL((trt::render_persistent_kernel<false, true>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+                hipLaunchKernelGGL((trt::render_persistent_kernel<false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f);
         }
         else if (count)
-            hipLaunchKernelGGL((trt::render_persistent_kernel<true, false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+            hipLaunchKernelGGL((trt::render_persistent_kernel<true, false>), grid, block, plds, stream, ctx->scene, ctx->cull, f);
         else
-            hipLaunchKernelGGL((trt::render_persistent_kernel<false, false>), grid, block, plds, ctx->stream, ctx->scene, ctx->cull, f);
+            hipLaunchKernelGGL((trt::render_persistent_kernel<false, false>), grid, block, plds, stream, ctx->scene, ctx->cull, f);
         if (sample_units)
         { // TRT.c:1063-1065: the mean over each pixel's samples, in sample order
             const long values = pixels * 3;
-            hipLaunchKernelGGL(trt::reduce_samples_kernel, dim3((unsigned)((values + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const double *)ctx->d_samples.ptr, (double *)d_pixels, values, rays_per_pixel, f.inv_spp);
+            hipLaunchKernelGGL(trt::reduce_samples_kernel, dim3((unsigned)((values + 255) / 256)), dim3(256), 0, stream,
+                               (const double *)scratch.ptr, (double *)d_pixels, values, rays_per_pixel, f.inv_spp);
         }
-        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
     }
     HIP_TRY(hipGetLastError());
     ctx->launches++;
@@ -887,13 +909,19 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
     // into the caller's (pageable) buffer.  Shards and small frames are one band.
     const int local_rows = trt_rowset_rows(rows);
     const bool whole = rows->tile_first == 0 && rows->tile_step == 1 && rows->tile_rows >= rows->height;
-    const int bands = whole && !ctx->counters_enabled && local_rows >= 256 && bytes >= (32u << 20) ? 4 : 1;
+    static const int band_count = getenv("TRT_HOST_BANDS") ? std::min(8, std::max(1, atoi(getenv("TRT_HOST_BANDS")))) : 4;
+    const int bands = whole && !ctx->counters_enabled && local_rows >= 256 && bytes >= (32u << 20) ? band_count : 1;
     const int band_rows = (local_rows + bands - 1) / bands;
     const size_t row_bytes = (size_t)rows->width * sizeof(Vector);
     const int chunks_per_band = (int)std::min<size_t>(16 / bands, std::max<size_t>(1, (size_t)band_rows * row_bytes / (4u << 20)));
     int chunks = 0;
     size_t chunk_at[16], chunk_len[16];
     const hipStream_t copy_stream = bands > 1 ? ctx->copy_stream : ctx->stream;
+    if (bands > 1)
+    { // the alternate stream starts behind whatever the caller queued on the context's stream before this call
+        HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->alt_stream, ctx->ev_fork, 0));
+    }
     for (int b = 0; b < bands; b++)
     {
         trt_rowset band = *rows;
@@ -901,12 +929,13 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
             band = trt_rowset{rows->width, rows->height, band_rows, b, bands};
         const int rows_here = trt_rowset_rows(&band);
         const size_t at = (size_t)b * band_rows * row_bytes, len = (size_t)rows_here * row_bytes;
-        int rc = trt_render_device(ctx, camera, &band, bounce_limit, rays_per_pixel, (char *)ctx->d_fb.ptr + at, len);
+        const int set = bands > 1 ? (b & 1) : 0; // odd bands on the alternate stream: a band's tail and reduction overlap the next band
+        int rc = render_device_on(ctx, camera, &band, bounce_limit, rays_per_pixel, (char *)ctx->d_fb.ptr + at, len, set);
         if (rc)
             return rc;
         if (bands > 1)
         { // a second stream costs ~0.1 ms of cross-queue hand-over: only where there is something to overlap
-            HIP_TRY(hipEventRecord(ctx->ev_band[b], ctx->stream));
+            HIP_TRY(hipEventRecord(ctx->ev_band[b], set ? ctx->alt_stream : ctx->stream));
             HIP_TRY(hipStreamWaitEvent(copy_stream, ctx->ev_band[b], 0));
         }
         const size_t per = ((len + chunks_per_band - 1) / chunks_per_band + 63) / 64 * 64;
@@ -950,7 +979,10 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
     for (int w = 0; w < workers; w++)
         HIP_TRY(worker_error[w]);
     if (bands > 1)
+    {
         HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->alt_stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (print_host_times())
         fprintf(stderr, "trt_render_host: %d band(s), enqueue %.3f ms, render + copy-out of %zu bytes %.3f ms\n", bands, t_enqueued - t_begin, bytes,
