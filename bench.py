@@ -22,6 +22,10 @@ import os
 import sys
 import time
 
+# every HIP stream of a process is dealt onto one of a few hardware queues (4 by default), and streams that share a queue
+# run one after the other: the render streams of the frames in flight, the assembly stream and RCCL's must not collide
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -480,8 +480,6 @@ static int init_context(trt_context *ctx)
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming));
     for (int i = 0; i < 8; i++)
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_band[i], hipEventDisableTiming));
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIP_TRY(ctx->d_counters.reserve(kCounterSlots));
     HIP_TRY(ctx->d_queue.reserve(64));
@@ -916,6 +914,12 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
     const int chunks_per_band = (int)std::min<size_t>(16 / bands, std::max<size_t>(1, (size_t)band_rows * row_bytes / (4u << 20)));
     int chunks = 0;
     size_t chunk_at[16], chunk_len[16];
+    if (bands > 1 && !ctx->copy_stream)
+    { // created on first use: every stream of a process competes for a handful of hardware queues, and two streams that
+      // land on one queue run one after the other (a renderer that never comes here keeps its streams to itself)
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking));
+    }
     const hipStream_t copy_stream = bands > 1 ? ctx->copy_stream : ctx->stream;
     if (bands > 1)
     { // the alternate stream starts behind whatever the caller queued on the context's stream before this call
