@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
     ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = 2 on one GPU, 3 on several)")
     ap.add_argument("--reserve-cus", type=int, default=-1, help="compute units kept free of render workgroups so that the gather's kernels can "
-                                                               "run beside them (-1 = 0 on one GPU, 8 on several)")
+                                                               "run beside them (-1 = 16 from 8 GPUs on, else 0)")
     args = ap.parse_args()
 
     import torch
@@ -118,8 +118,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if args.depth <= 0:
         args.depth = 2 if world == 1 else 3
-    if args.reserve_cus < 0:
-        args.reserve_cus = 0 if world == 1 else 8
+    if args.reserve_cus < 0:  # pays only where a rank's frame is short against the gather (tools/gather_sim.py)
+        args.reserve_cus = 16 if world >= 8 else 0
     local = local % max(1, torch.cuda.device_count())  # rehearsals may put several ranks on one GPU
     if world > 1:
         if args.backend == "nccl":

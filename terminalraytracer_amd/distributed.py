@@ -82,10 +82,10 @@ class HipShardRenderer:
     """Product path: this rank's row tiles rendered by libtrt_hip.so into a shard tensor, frames PIPELINED.
 
     `depth` renderer contexts, each with its own HIP stream, shard buffer and gather buffers, take the frames
-    round-robin.  For world > 1 use depth 3 and reserve a few compute units (`reserve_cus`): the persistent workgroups of
-    the next frame otherwise keep the gather's kernels (and this frame's reduction) off the machine until that frame has
-    drained, and a frame costs render + gather instead of max(render, gather) (tools/gather_sim.py: 0.57 -> 0.30 ms per
-    1/8 shard with a 0.2 ms stand-in for the gather).  A persistent-wave frame ends with a tail in which most CUs are already idle; with two frames
+    round-robin.  For world > 1 use depth 3, and where a rank's frame is short (8 GPUs at 1080p) reserve some compute units
+    (`reserve_cus`): the persistent workgroups of the next frame otherwise keep the gather's kernels (and this frame's
+    reduction) off the machine until that frame has drained (tools/gather_sim.py: 0.37 -> 0.28 ms per 1/8 shard with a
+    0.2 ms stand-in for the gather, 16 CUs reserved).  A persistent-wave frame ends with a tail in which most CUs are already idle; with two frames
     in flight the next frame's workgroups fill those CUs (measured on one MI355X at 1080p: 3.33 -> 2.98 ms per
     whole frame, 0.64 -> 0.38 ms per 1/8 shard), and the gather of frame f overlaps the rendering of f+1.
     Ordering is by events: a slot renders only after the assembly of its previous frame was enqueued, and the

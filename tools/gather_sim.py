@@ -46,7 +46,7 @@ for world in (8, 2):
             for k in range(2 * depth + 4):
                 frame(k)
             torch.cuda.synchronize()
-            n = 60
+            n = 200
             t0 = time.perf_counter()
             for k in range(2 * depth + 4, 2 * depth + 4 + n):
                 frame(k)
