@@ -106,25 +106,22 @@ class HipShardRenderer:
         for _ in range(max(1, depth)):
             ctx = hip.Context(local_device)
             ctx.set_scene(scene_data)
-            stream = None
             if reserve_cus > 0:
                 try:
-                    ctx.reserve_cus(reserve_cus)  # the library's own stream, with a CU mask; torch only needs its handle
-                    stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=torch.device(f"cuda:{local_device}"))
-                except Exception as e:  # an optimisation only: render on an ordinary stream if the mask cannot be had
+                    ctx.reserve_cus(reserve_cus)  # re-creates the context's own stream with a CU mask
+                except Exception as e:  # an optimisation only: render on the ordinary stream if the mask cannot be had
                     import sys
                     print(f"HipShardRenderer: no compute units reserved ({type(e).__name__}: {e})", file=sys.stderr)
-                    ctx.reserve_cus(0)
                     reserve_cus = 0
-            if stream is None:
-                stream = torch.cuda.Stream(device=local_device)
-                ctx.set_stream(stream.cuda_stream)
+            # the context's own stream, wrapped for torch's event calls: one stream per renderer and no more (every stream
+            # of the process competes for a few hardware queues, and streams sharing a queue run one after the other)
+            stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=torch.device(f"cuda:{local_device}"))
             frame = ShardedFrame(width, height, rank, world, f"cuda:{local_device}", tile_rows,
                                  dtype=torch.uint8 if rgb8 else torch.float64)
             self.slots.append({"ctx": ctx, "stream": stream, "frame": frame,
                                "pixels": torch.zeros((frame.max_rows, width, 3), dtype=torch.float64, device=f"cuda:{local_device}") if rgb8 else frame.shard,
                                "rendered": torch.cuda.Event(), "consumed": torch.cuda.Event()})
-        self.external_streams = reserve_cus > 0
+        self.external_streams = reserve_cus > 0  # CU-masked render streams
         # CU-masked streams are "blocking" streams: they order themselves against the NULL stream.  With them, the
         # assembly (wait, gather, index_select) runs on a stream of its own so that nothing in the loop touches stream 0.
         self.main = torch.cuda.Stream(device=local_device) if self.external_streams else None
@@ -168,6 +165,4 @@ class HipShardRenderer:
     def close(self):
         torch.cuda.synchronize()
         for slot in self.slots:
-            if not self.external_streams:
-                slot["ctx"].set_stream(None)
             slot["ctx"].close()
