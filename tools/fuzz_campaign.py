@@ -37,8 +37,23 @@ def wide_scene(rng, w, h):
     return S.SceneData(sph, ground, dl.reshape(-1, 6), pl.reshape(-1, 7), cam, T.sky("synth"))
 
 
+def light_heavy_scene(rng, w, h):
+    """Up to six lights of each kind: directions of any magnitude (1e-7 .. 1e3: below 1e-4 the reference leaves them
+    un-normalised, TRT.c:444), duplicated lights, lights inside spheres, far and near, zero and negative colours."""
+    scene = P._fuzz_scene(rng, w, h)
+    nd, npt = int(rng.integers(0, 7)), int(rng.integers(0, 7))
+    dl = np.concatenate([rng.normal(size=(nd, 3)) * 10.0 ** rng.uniform(-7, 3, (nd, 1)), rng.uniform(-0.3, 1.2, (nd, 3))], axis=1)
+    pl = np.concatenate([rng.normal(size=(npt, 3)) * 10.0 ** rng.uniform(-1, 2, (npt, 1)), rng.uniform(-0.3, 1.2, (npt, 3)),
+                         rng.uniform(0.0, 50.0, (npt, 1))], axis=1)
+    if nd >= 2:
+        dl[1] = dl[0]
+    if npt >= 2 and len(scene.spheres):
+        pl[1, :3] = scene.spheres[0, :3]            # a light at a sphere's centre
+    return S.SceneData(scene.spheres, scene.ground, dl.reshape(-1, 6), pl.reshape(-1, 7), scene.camera, scene.sky)
+
+
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
-make = wide_scene if len(sys.argv) > 3 and sys.argv[3] == "wide" else P._fuzz_scene
+make = {"wide": wide_scene, "lights": light_heavy_scene}.get(sys.argv[3] if len(sys.argv) > 3 else "", P._fuzz_scene)
 bad = 0
 with hip.Context(0) as ctx:
     for seed in range(first, first + count):
