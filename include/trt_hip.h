@@ -13,7 +13,9 @@
  *
  * All functions returning int return TRT_OK (0) or a negative TRT_ERR_*; trt_last_error()
  * gives the message.  A context is bound to one device and one stream and is not
- * thread-safe; separate contexts are independent.
+ * thread-safe; separate contexts are independent.  The drop-in layer (project_scene, trt_render_frame,
+ * trt_init/shutdown, trt_upload/invalidate_skybox) shares one default context and takes a lock: like the
+ * reference's pure function it may be called from several threads, the calls then take turns.
  */
 #ifndef TRT_HIP_H
 #define TRT_HIP_H

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -1122,6 +1123,9 @@ namespace
 {
 trt_context *g_default = nullptr;
 int g_default_device = 0;
+// The reference's project_scene is a pure function of its arguments and may be called from several threads; the drop-in
+// shares one device context, so calls on the default context take turns.
+std::mutex g_default_mutex;
 
 int default_context(trt_context **out)
 {
@@ -1138,6 +1142,7 @@ int default_context(trt_context **out)
 
 extern "C" int trt_init(int device)
 {
+    std::lock_guard<std::mutex> turn(g_default_mutex);
     if (g_default && g_default->device != device)
     {
         trt_destroy(g_default);
@@ -1150,6 +1155,7 @@ extern "C" int trt_init(int device)
 
 extern "C" int trt_shutdown(void)
 {
+    std::lock_guard<std::mutex> turn(g_default_mutex);
     int rc = trt_destroy(g_default);
     g_default = nullptr;
     return rc;
@@ -1157,6 +1163,7 @@ extern "C" int trt_shutdown(void)
 
 extern "C" int trt_upload_skybox(const Skybox *skybox)
 {
+    std::lock_guard<std::mutex> turn(g_default_mutex);
     if (!skybox)
         return fail(TRT_ERR_ARGUMENT, "skybox is NULL");
     trt_context *ctx;
@@ -1170,6 +1177,7 @@ extern "C" int trt_upload_skybox(const Skybox *skybox)
 
 extern "C" int trt_invalidate_skybox(void)
 {
+    std::lock_guard<std::mutex> turn(g_default_mutex);
     if (g_default)
         g_default->sky_dim = -1;
     return TRT_OK;
@@ -1181,6 +1189,7 @@ extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_l
         return fail(TRT_ERR_ARGUMENT, "NULL argument");
     if (screen->width <= 0 || screen->height <= 0)
         return fail(TRT_ERR_ARGUMENT, "screen %d x %d", screen->width, screen->height);
+    std::lock_guard<std::mutex> turn(g_default_mutex);
     trt_context *ctx;
     int rc = default_context(&ctx);
     if (rc)

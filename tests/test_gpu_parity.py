@@ -508,3 +508,16 @@ def test_lean_normalisation_and_sqrt_equal_the_plain_operators(ctx):
     assert ok.all(), int((~ok).sum())
     ok = (bits(ref[:, 3]) == bits(host_root)) | (np.isnan(ref[:, 3]) & np.isnan(host_root))
     assert ok.all(), int((~ok).sum())
+
+
+def test_drop_in_symbol_may_be_called_from_several_threads(tmp_path):
+    """The reference's project_scene is a pure function; a host may call it from several threads.  The drop-in layer shares
+    one device context behind a lock: four threads x five calls must all produce the same frame."""
+    import os
+    import subprocess
+    exe = str(tmp_path / "mt_drop_in")
+    libdir = os.path.join(T.ROOT, "terminalraytracer_amd")
+    subprocess.check_call(["gcc", "-O1", "-I" + os.path.join(T.ROOT, "include"), "-o", exe, os.path.join(T.ROOT, "tests", "mt_drop_in.c"),
+                           "-L" + libdir, "-ltrt_hip", "-Wl,-rpath," + libdir, "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "identical" in out.stdout, out.stdout + out.stderr
