@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X frame producer.
 
-Workload (BASELINE.json metric / configs[2], SURVEY.md 8d "C3"): one 1920x1080 frame of the
+Default workload (BASELINE.json metric / configs[2], SURVEY.md 8d "C3"): one 1920x1080 frame of the
 SYNTH-v0 scene (64 random spheres, seed 1234, mixed reflectivity) + checker floor + 2 lights,
 8 bounces, 10 rays per pixel, 256^2 procedural cubemap.  A step = one frame.  Scene, cubemap
 and camera are resident on the GPU before the timed region; frames are rendered into device
 memory ("off-screen framebuffer").
+
+--animation F (BASELINE configs[4], "C5"): 256 spheres, 12 bounces, the reference's orbiting camera
+(TerminalRayTracer.c:1327-1336) at t = f/60, f = 0..F-1, a NEW camera every step; reports sustained
+frames/s next to path rays/s.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is sharded by
 interleaved 8-row tiles across the ranks and assembled on rank 0 with one RCCL gather per
@@ -14,6 +18,11 @@ frame ("scaling": "strong").
 metric: path rays/s = trace calls issued by the bounce loop (primary + secondary rays,
 TRT.c:1024) per second.  The per-frame ray count is deterministic; it is taken once from the
 kernel's counting variant in an UNTIMED pass (the timed kernel carries no counters).
+
+The frame that is timed is CHECKED: after the timed loop rank 0 hashes the last frame (FNV-1a-64 of the
+double framebuffer, untimed) and compares it with the hash the GENUINE reference produced for the same
+scene and camera (tests/golden/golden_full.json, made by tests/golden/make_golden_full.py); a wrong
+pixel anywhere fails the run (exit code 3, "verified": false in the line).
 """
 import argparse
 import ctypes as C
@@ -31,15 +40,56 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-W, H, SPHERES, BOUNCES, SPP, SKY_DIM, SEED = 1920, 1080, 64, 8, 10, 256, 1234
+SPP, SKY_DIM, SEED = 10, 256, 1234
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_PEAK_TFLOPS = 78.6      # FP64 vector with FMA; 39.3 without (contraction must stay off here)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+WORKLOADS = {
+    # name: (width, height, spheres, bounce limit, golden case of the frame at orbit time 1.0 / of animation frames)
+    "c3": dict(width=1920, height=1080, spheres=64, bounces=8, golden={1.0: "c3_1080p_64sph_b8"},
+               text="BASELINE configs[2]: 1920x1080, SYNTH-v0 64 spheres seed 1234 + checker floor, 1 directional + 1 point light, "
+                    "8 bounces, 10 rays/pixel, 256^2 procedural cubemap, off-screen f64 framebuffer"),
+    "c5": dict(width=1920, height=1080, spheres=256, bounces=12, golden={0: "c5_1080p_256sph_b12_f0", 59: "c5_1080p_256sph_b12_f59"},
+               text="BASELINE configs[4]: 1920x1080, SYNTH-v0 256 spheres seed 1234 + checker floor, 1 directional + 1 point light, "
+                    "12 bounces, 10 rays/pixel, 256^2 procedural cubemap, orbiting camera t = f/60 (a new camera every frame), "
+                    "off-screen f64 framebuffer"),
+}
 
 
-def build_scene():
+def stored_camera(width, height, t=1.0):
+    """The reference's own orbit camera at time t (tests/golden/cameras.npz, dumped from the genuine reference: libm's
+    sin/cos may differ in the last place between boxes) with screen_width = 5*W/H."""
+    d = np.load(os.path.join(GOLDEN, "cameras.npz"))
+    i = int(np.argmin(np.abs(d["t"] - t)))
+    assert abs(d["t"][i] - t) < 1e-12, t
+    cam = d["camera"][i].copy()
+    cam[13] = 5 * float(width) / float(height)
+    return cam
+
+
+def animation_cameras(width, height, frames):
+    d = np.load(os.path.join(GOLDEN, "cameras_anim.npz"))
+    cams = d["camera"][np.arange(frames) % len(d["t"])].copy()
+    cams[:, 13] = 5 * float(width) / float(height)
+    return [c for c in cams]
+
+
+def build_scene(workload="c3"):
     from terminalraytracer_amd import scenes as S
-    cam = S.orbit_camera(1.0, W, H)
-    return S.synth_scene(SPHERES, S.synth_sky(SKY_DIM), cam, seed=SEED)
+    w = WORKLOADS[workload]
+    return S.synth_scene(w["spheres"], S.synth_sky(SKY_DIM), stored_camera(w["width"], w["height"], 1.0), seed=SEED)
+
+
+# names kept for the tools/ scripts
+W, H, SPHERES, BOUNCES = 1920, 1080, 64, 8
+
+
+def golden_hash(name):
+    with open(os.path.join(GOLDEN, "golden_full.json")) as fh:
+        for c in json.load(fh)["cases"]:
+            if c["name"] == name:
+                return c
+    raise KeyError(name)
 
 
 def algorithmic_bytes(width, height, n, dim, ld, lp):
@@ -47,33 +97,36 @@ def algorithmic_bytes(width, height, n, dim, ld, lp):
     return width * height * 24 + 6 * dim * dim * 3 + n * 72 + 352 + 48 * ld + 56 * lp
 
 
-def cpu_baseline(scene):
+def cpu_baseline(scene, width, height, bounces, full_frame):
     """Reference CPU path on this box's host cores: the genuine reference (oracle/_ref, compiled from the
-    reference's own file) renders ONE frame of the same workload, single-threaded like the original
-    (about 10-15 s of CPU work).  Falls back to the repo's restatement ("port") where the reference
-    library is absent.  The all-core OpenMP port is reported beside it."""
+    reference's own file) renders a bounded sample of the same workload, single-threaded like the original:
+    the whole 1080p frame for the 64-sphere workload (10-15 s), the same scene and camera at 480x270 for the
+    256-sphere one (a full frame would take minutes).  Falls back to the repo's restatement ("port") where the
+    reference library is absent.  The all-core OpenMP port is reported beside it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import support as T
     from terminalraytracer_amd import layout as L
     from terminalraytracer_amd import scenes as S
+    w, h = (width, height) if full_frame else (480, 270)
     threads = min(os.cpu_count() or 1, 64)
     t0 = time.perf_counter()
-    _, st = T.oracle_render(scene, W, H, BOUNCES, SPP, threads=threads)  # also yields the ray count of the frame
+    _, st = T.oracle_render(scene, w, h, bounces, SPP, threads=threads)  # also yields the ray count of the sample
     dt_all = time.perf_counter() - t0
-    ref = os.path.join(ROOT, "oracle", "_ref", f"libtrtref_b{BOUNCES}_s{SPP}_w480_h280.so")
-    out = {"unit": "path rays/s", "cores": 1, "sample": f"1 full {W}x{H} frame of the same scene/camera (the whole step)"}
+    ref = os.path.join(ROOT, "oracle", "_ref", f"libtrtref_b{bounces}_s{SPP}_w480_h280.so")
+    out = {"unit": "path rays/s", "cores": 1,
+           "sample": f"1 {w}x{h} frame of the same scene/camera" + (" (the whole step)" if full_frame else " (1/16 of the step's pixels)")}
     if os.path.exists(ref):
         lib = C.CDLL(ref)
         lib.project_scene.argtypes = [C.POINTER(L.Scene), C.POINTER(L.Screen)]
         sc = scene.as_scene()
-        screen, px = S.new_screen(W, H)
+        screen, px = S.new_screen(w, h)
         t0 = time.perf_counter()
         lib.project_scene(C.byref(sc), C.byref(screen))
         dt = time.perf_counter() - t0
         out.update(kind="reference", value=st.path_rays / dt, seconds=dt)
     else:
         t0 = time.perf_counter()
-        T.oracle_render(scene, W, H, BOUNCES, SPP, threads=1)
+        T.oracle_render(scene, w, h, bounces, SPP, threads=1)
         dt = time.perf_counter() - t0
         out.update(kind="port", value=st.path_rays / dt, seconds=dt)
     out["port_all_cores"] = {"value": st.path_rays / dt_all, "cores": threads, "seconds": dt_all}
@@ -81,35 +134,37 @@ def cpu_baseline(scene):
     return out
 
 
-def measured_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/traffic.json; FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied)."""
+def committed_profile():
+    """HBM bytes per launch and VALU counters from the COMMITTED rocprofv3 PMC passes of this same command
+    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied).  They are not
+    measured in this run: the record says which commit's kernel they were taken with."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(path):
-        return None, None
+        return None
     with open(path) as fh:
-        t = json.load(fh)
-    return t.get("hbm_bytes_per_launch"), t
+        return json.load(fh)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=0, help="timed frames (default 20; 60 with --animation)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--animation", type=int, default=0, metavar="F",
+                    help="config 5: 256 spheres, 12 bounces, orbit cameras t = f/60 for f < F, a new camera every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed frame against the reference's hash")
     ap.add_argument("--kernel", type=int, default=0, help="0 production, 1 reference-order (debug)")
-    ap.add_argument("--units", type=int, default=0, help="work units of the production kernel: 0 auto, 1 pixels, 2 samples")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
-    ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = 2 on one GPU, 3 on several)")
-    ap.add_argument("--reserve-cus", type=int, default=-1, help="compute units kept free of render workgroups so that the gather's kernels can "
-                                                               "run beside them (-1 = 16 from 8 GPUs on, else 0)")
+    ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = 2)")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="compute units kept free of render workgroups so that the gather's kernels can "
+                                                              "run beside them (a guess until an 8-GPU run has been made: default 0)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from terminalraytracer_amd import hip
+    from terminalraytracer_amd import hip, host
     from terminalraytracer_amd.distributed import HipShardRenderer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,9 +172,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if args.depth <= 0:
-        args.depth = 2 if world == 1 else 3
-    if args.reserve_cus < 0:  # pays only where a rank's frame is short against the gather (tools/gather_sim.py)
-        args.reserve_cus = 16 if world >= 8 else 0
+        args.depth = 2
+    workload = "c5" if args.animation > 0 else "c3"
+    wl = WORKLOADS[workload]
+    width, height, bounces = wl["width"], wl["height"], wl["bounces"]
+    if args.steps <= 0:
+        args.steps = args.animation if args.animation > 0 else 20
     local = local % max(1, torch.cuda.device_count())  # rehearsals may put several ranks on one GPU
     if world > 1:
         if args.backend == "nccl":
@@ -128,29 +186,45 @@ def main():
             dist.init_process_group(args.backend)
     torch.cuda.set_device(local)
 
-    scene = build_scene()
-    r = HipShardRenderer(scene, W, H, rank, world, local, BOUNCES, SPP, depth=args.depth, reserve_cus=args.reserve_cus)
-    r.for_each_context(lambda c: (c.set_kernel(args.kernel), c.set_work_units(args.units)))
+    scene = build_scene(workload)
+    cameras = animation_cameras(width, height, args.animation) if args.animation > 0 else [scene.camera]
+    camera_of = lambda step: cameras[step % len(cameras)]  # noqa: E731
+    r = HipShardRenderer(scene, width, height, rank, world, local, bounces, SPP, depth=args.depth, reserve_cus=args.reserve_cus)
+    r.for_each_context(lambda c: c.set_kernel(args.kernel))
 
-    # untimed: per-frame ray counts of this rank's rows (counting variant of the kernel)
+    # untimed: ray counts of this rank's rows for every distinct camera (counting variant of the kernel)
     r.ctx.enable_counters(True)
-    r.render(scene.camera)
-    torch.cuda.synchronize()
-    path_rays, shadow_rays = r.ctx.read_counters()
-    diag = r.ctx.read_diagnostics()
+    path_per_cam, shadow_per_cam, diag = [], [], None
+    for cam in cameras:
+        r.ctx.render_device(cam, r.sharded.rowset, bounces, SPP, r.slots[0]["pixels"].data_ptr(), r.slots[0]["pixels"].numel() * 8)
+        p, s = r.ctx.read_counters()
+        path_per_cam.append(p)
+        shadow_per_cam.append(s)
+        diag = diag or r.ctx.read_diagnostics()
     r.ctx.enable_counters(False)
-    for _ in range(args.depth - 1):  # bring every slot to the same state before warm-up
-        r.render(scene.camera)
     torch.cuda.synchronize()
-    counts = torch.tensor([path_rays, shadow_rays], dtype=torch.float64, device=f"cuda:{local}")
+    counts = torch.tensor([path_per_cam, shadow_per_cam], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
         dist.all_reduce(counts)
-    path_total, shadow_total = float(counts[0].item()), float(counts[1].item())
+    path_cam, shadow_cam = counts[0].cpu().numpy(), counts[1].cpu().numpy()
+    path_timed = float(sum(path_cam[i % len(cameras)] for i in range(args.steps)))
+    shadow_timed = float(sum(shadow_cam[i % len(cameras)] for i in range(args.steps)))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # untimed: strictly one frame at a time on ONE context, every launch bracketed by HIP events on its stream; the render
+    # kernel's own duration (the roofline's denominator) and the ordered-mean kernel's behind it
+    d1 = min(args.steps, 20)
+    px0 = r.slots[0]["pixels"]
+    for i in range(2 + d1):
+        r.ctx.render_device(camera_of(i), r.sharded.rowset, bounces, SPP, px0.data_ptr(), px0.numel() * 8)
+        r.ctx.synchronize()
+    render_ms, reduce_ms = r.ctx.render_kernel_times(d1)
+    render_ms_avg, reduce_ms_avg = float(np.mean(render_ms)), float(np.mean(reduce_ms))
+    barrier()
 
     if args.check:  # the sharded, gathered frame must equal the frame of one renderer, bit for bit
         frame = r.render(scene.camera)
@@ -158,71 +232,94 @@ def main():
         if rank == 0:
             with hip.Context(local) as single:
                 single.set_scene(scene)
-                whole = single.render_host(scene.camera, hip.RowSet.whole(W, H), BOUNCES, SPP)
+                whole = single.render_host(scene.camera, hip.RowSet.whole(width, height), bounces, SPP)
             same = np.array_equal(frame.cpu().numpy().view(np.uint64), whole.view(np.uint64))
             print(f"CHECK sharded({world}) == single: {same}", file=sys.stderr)
             assert same
-        for _ in range(args.depth - 1):
-            r.render(scene.camera)
         barrier()
 
-    for _ in range(args.warmup):
-        r.render(scene.camera)
+    for i in range(args.warmup):
+        r.render(camera_of(i))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r.render(scene.camera)
+    last = None
+    for i in range(args.steps):
+        last = r.render(camera_of(i))
     barrier()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     seconds = float(elapsed.item())
 
-    kernel_ms = r.kernel_times(args.steps)  # HIP events on each launch stream, the timed launches only
+    # untimed: the frame the timed loop produced last (and, for the animation, frame 59) against the GENUINE reference's hash
+    verified, checks = None, []
+    if not args.no_verify:
+        probes = [((args.steps - 1) % len(cameras), last)]
+        if args.animation > 59 and (args.steps - 1) % len(cameras) != 59:
+            probes.append((59, None))
+        for index, frame in probes:
+            key = index if args.animation > 0 else 1.0
+            if key not in wl["golden"]:
+                continue
+            if frame is None:
+                frame = r.render(cameras[index])
+            torch.cuda.synchronize()
+            if rank == 0:
+                want = golden_hash(wl["golden"][key])
+                got = host.fnv1a64(frame.cpu().numpy())
+                checks.append({"frame": wl["golden"][key], "fnv": got, "reference_fnv": want["fb_fnv"], "ok": got == want["fb_fnv"]})
+            barrier()
+        if rank == 0:
+            verified = bool(checks) and all(c["ok"] for c in checks)
+
     if rank == 0:
         ms_step = seconds / args.steps * 1e3
-        kavg = float(np.mean(kernel_ms))
         rows = hip.lib().trt_rowset_rows(C.byref(r.sharded.rowset))
-        alg = algorithmic_bytes(W, rows, SPHERES, SKY_DIM, scene.dir_lights.shape[0], scene.point_lights.shape[0])
-        achieved = alg / (kavg * 1e-3) / 1e9
-        flops = (path_total + shadow_total) / world * (25 * SPHERES + 17)  # SURVEY 8(d) reference op count, per rank
+        nd, npt = scene.dir_lights.shape[0], scene.point_lights.shape[0]
+        alg = algorithmic_bytes(width, rows, wl["spheres"], SKY_DIM, nd, npt)
+        achieved = alg / (render_ms_avg * 1e-3) / 1e9
+        path_mean = float(np.mean(path_cam))
+        prof = committed_profile() if (world == 1 and workload == "c3") else None
         out = {
-            "metric": "path rays/s (primary+secondary) at 1920x1080, 64 spheres, 8 bounces",
-            "value": path_total * args.steps / seconds,
+            "metric": "path rays/s (primary+secondary) at 1920x1080, 64 spheres, 8 bounces" if workload == "c3" else
+                      "path rays/s (primary+secondary) at 1920x1080, 256 spheres, 12 bounces, orbiting camera",
+            "value": path_timed / seconds,
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 1920x1080, SYNTH-v0 64 spheres seed 1234 + checker floor, "
-                                   "1 directional + 1 point light, 8 bounces, 10 rays/pixel, 256^2 procedural cubemap, "
-                                   "off-screen f64 framebuffer", "sharding": f"{world} x interleaved 8-row tiles, 1 gather/frame",
-                       "kernel": {0: "persistent waves, synchronous rounds", 1: "reference-order", 2: "persistent state machine"}[args.kernel],
+            "config": {"workload": wl["text"], "sharding": f"{world} x interleaved 8-row tiles, 1 gather/frame",
+                       "kernel": {0: "persistent waves, synchronous rounds", 1: "reference-order"}[args.kernel],
                        "frames_in_flight": args.depth, "reserved_cus": args.reserve_cus},
-            "rays_per_frame": {"path": path_total, "shadow": shadow_total},
-            "all_rays_per_s": (path_total + shadow_total) * args.steps / seconds,
-            "kernel_ms_avg": kavg,
+            "frames_per_s": args.steps / seconds,
+            "rays_per_frame": {"path": path_mean, "shadow": float(np.mean(shadow_cam))},
+            "all_rays_per_s": (path_timed + shadow_timed) / seconds,
             "frames_in_flight": args.depth,
+            "verified": verified, "verification": checks,
+            # one frame at a time (no overlap between consecutive frames): render kernel + ordered mean, HIP events per launch
+            "one_frame_at_a_time": {"render_kernel_ms": render_ms_avg, "reduce_kernel_ms": reduce_ms_avg, "launches": d1,
+                                    "path_rays_per_s": path_mean / ((render_ms_avg + reduce_ms_avg) * 1e-3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic()[0] if world == 1 else None,
-                         "algorithmic_bytes": alg,
-                         "note": "VALU-issue-bound path: algorithmic HBM bytes are ~1 B/ray (SURVEY 8d); see fp64_valu and DESIGN.md 5. "
-                                 "achieved = algorithmic bytes per launch / average launch duration (HIP events); with "
-                                 "frames_in_flight > 1 launches overlap, so a launch lasts longer than ms_per_step"},
-            "fp64_valu": {"achieved_tflops_reference_opcount": flops / (kavg * 1e-3) / 1e12, "peak_tflops_fma": FP64_PEAK_TFLOPS,
-                          "peak_tflops_no_fma": FP64_PEAK_TFLOPS / 2,
-                          "note": "reference op count 25*N+17 per trace; the kernel does fewer ops than that (FP32 culling)"},
-            "valu_issue": (measured_traffic()[1] or {}).get("valu"),  # committed PMC summary of this same command
+                         "traffic": (prof or {}).get("hbm_bytes_per_launch"),
+                         "traffic_source": (prof or {}).get("source"),
+                         "algorithmic_bytes": alg, "kernel": "render_rounds_kernel<false>", "kernel_ms": render_ms_avg,
+                         "achieved_by_step": alg / (ms_step * 1e-3) / 1e9,
+                         "note": "achieved = algorithmic bytes of a frame (SURVEY 8d) / the render kernel's own average duration, HIP events "
+                                 "on its stream, frames launched strictly one at a time (one_frame_at_a_time); the timed region keeps "
+                                 "frames_in_flight frames in flight, so consecutive launches overlap there.  The path is VALU-issue-bound: "
+                                 "~1 algorithmic byte per ray, frac << 1 by nature (SURVEY 0, DESIGN.md 5); `traffic` and `valu` are "
+                                 "COMMITTED rocprofv3 PMC results (profiles/traffic.json), not measured in this run"},
+            "valu": (prof or {}).get("valu"),
             "kernel_info": r.ctx.kernel_info(),
-            # rounds kernel (id 0): one round = one path ray per lane (+ one shadow ray per light for the lanes that hit something)
-            "diagnostics": dict(diag, path_lane_utilisation=path_rays / max(1, 64 * diag["wave_loop_trips"]),
-                                shadow_lane_utilisation=shadow_rays / max(1, 64 * diag["wave_loop_trips"] * max(1, scene.dir_lights.shape[0] + scene.point_lights.shape[0])),
-                                exact_test_rounds_per_trace=diag["phase2_rounds"] / max(1, path_rays + shadow_rays) * 64)
-            if args.kernel == 0 and args.units != 1 else
-            dict(diag, lane_utilisation=(path_rays + shadow_rays) / max(1, 64 * diag["wave_loop_trips"])),
+            # one round = one path ray per lane (+ one shadow ray per light for the lanes that hit something)
+            "diagnostics": dict(diag, path_lane_utilisation=path_per_cam[0] / max(1, 64 * diag["wave_loop_trips"]),
+                                shadow_lane_utilisation=shadow_per_cam[0] / max(1, 64 * diag["wave_loop_trips"] * max(1, nd + npt)),
+                                exact_test_rounds_per_trace=diag["phase2_rounds"] / max(1, path_per_cam[0] + shadow_per_cam[0]) * 64)
+            if args.kernel == 0 else diag,
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(scene)
+                out["cpu_baseline"] = cpu_baseline(scene, width, height, bounces, full_frame=(workload == "c3"))
             except Exception as e:  # the checker libraries are built by __graft_entry__.build(); never lose the GPU line over them
                 out["cpu_baseline"] = {"value": None, "unit": "path rays/s", "cores": 1, "kind": "port", "sample": "not measured",
                                        "error": f"{type(e).__name__}: {e}"}
@@ -230,6 +327,9 @@ def main():
     r.close()
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and verified is False:
+        print("bench.py: the timed frame differs from the reference's frame: " + json.dumps(checks), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -118,6 +118,9 @@ int trt_synchronize(trt_context *ctx);
 /* HIP-event durations (ms) of the most recent render-kernel launches on this context, newest
  * last; returns how many were written (<= max).  Synchronises the stream. */
 int trt_kernel_times(trt_context *ctx, float *ms, int max);
+/* The same launches split at the HIP event recorded between the two kernels of a frame: the render kernel's own
+ * duration and that of the ordered mean over a pixel's samples (TRT.c:1063-1065); reduce_ms may be NULL. */
+int trt_render_kernel_times(trt_context *ctx, float *render_ms, float *reduce_ms, int max);
 
 /* Work counters of the LAST rendered frame (device atomics, only when enabled; off by default
  * so timed runs carry no atomics).  path = trace calls from the bounce loop (TRT.c:1024),
@@ -130,16 +133,11 @@ int trt_read_counters(trt_context *ctx, unsigned long long *path_rays, unsigned 
  * Lane utilisation of the trace loop = (path + shadow) / (64 * wave_loop_trips). */
 int trt_read_diagnostics(trt_context *ctx, unsigned long long *wave_loop_trips, unsigned long long *phase2_rounds);
 
-/* Kernel selection: 0 = production kernel (persistent waves, mode-synchronous rounds); 1 = reference-order
- * debugging kernel (one lane per pixel, no culling); 2 = the earlier production design (persistent waves,
- * per-lane state machine), kept for A/B measurements.  All are HIP; there is no CPU path. */
+/* Kernel selection: 0 = production kernel (persistent waves, mode-synchronous rounds over single samples, then the
+ * ordered mean per pixel); 1 = reference-order kernel (one lane per pixel, loops exactly as TRT.c:966-1069, every
+ * sphere tested, no culling): an independent implementation kept as the on-device parity anchor.  Both are HIP; there
+ * is no CPU path. */
 int trt_set_kernel(trt_context *ctx, int which);
-
-/* Work units of the production kernel: 0 = automatic (default), 1 = whole pixels (the lane keeps the running
- * mean of TRT.c:1063), 2 = single samples (per-sample colours go to a scratch buffer, a second kernel forms
- * the mean in the reference's order).  Samples balance ten times finer and are chosen automatically when a
- * frame (or a GPU's shard of it) has few pixels per resident lane; results are bit-identical either way. */
-int trt_set_work_units(trt_context *ctx, int units);
 
 /* Light-space candidate masks of the production kernel (csrc/trt_lightgrid.h): a shadow ray reads the spheres it can
  * touch from a table of its light -- a directional_cells^2 grid across a directional light's direction, a cube map

@@ -60,14 +60,20 @@ int trt_emitter_create(int width, int height, trt_emitter **out);
 void trt_emitter_destroy(trt_emitter *e);
 const char *trt_emitter_buffer(const trt_emitter *e);
 size_t trt_emitter_size(const trt_emitter *e);
-/* TRT.c:1142-1168: patch the 9 digits of every cell with (int)(c*255) (no output yet) */
-void trt_emitter_patch(trt_emitter *e, const Screen *screen);
-/* the same from bytes already quantised on the GPU (trt_quantize_device): 3 bytes per pixel */
-void trt_emitter_patch_rgb8(trt_emitter *e, const unsigned char *rgb);
+/* TRT.c:1142-1168: patch the 9 digits of every cell with (int)(c*255) (no output yet).  The Screen must have the
+ * emitter's width and height (in the reference both come from SCREEN_WIDTH/HEIGHT): TRT_HOST_ERR_ARGUMENT otherwise. */
+int trt_emitter_patch(trt_emitter *e, const Screen *screen);
+/* the same from bytes already quantised on the GPU (trt_quantize_device): 3 bytes per pixel, width*height pixels */
+int trt_emitter_patch_rgb8(trt_emitter *e, const unsigned char *rgb);
 /* TRT.c:1171: one fwrite of the whole buffer (trailing NULs included, as the reference does) */
 int trt_emitter_write(const trt_emitter *e, FILE *stream);
 /* TRT.c:1084-1099: the unbuffered printf form */
 int trt_draw_screen(const Screen *screen, FILE *stream);
+
+/* ---- frame fingerprint ------------------------------------------------------------------ */
+/* FNV-1a-64 (offset 1469598103934665603, prime 1099511628211) over raw bytes: the hash the golden frames are recorded
+ * with, e.g. over screen->pixels[0 .. W*H) after project_scene (TRT.c:966). */
+unsigned long long trt_fnv1a64(const void *data, size_t bytes);
 
 #ifdef __cplusplus
 }

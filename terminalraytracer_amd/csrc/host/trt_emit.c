@@ -75,8 +75,12 @@ static void three_digits(char *at, int value)
     at[2] = (char)(value % 10 + '0');
 }
 
-void trt_emitter_patch(trt_emitter *e, const Screen *screen)
+int trt_emitter_patch(trt_emitter *e, const Screen *screen)
 {
+    /* the reference's buffer and Screen share SCREEN_WIDTH/HEIGHT (TRT.c:47-48, :1104); here they are run-time values
+     * and must agree, or the walk below would leave the buffer */
+    if (!e || !screen || !screen->pixels || screen->width != e->width || screen->height != e->height)
+        return TRT_HOST_ERR_ARGUMENT;
     char *row_text = e->text + HOME_LEN;
     for (int row = 0; row < screen->height; row++, row_text += (size_t)CELL_LEN * e->width + 1)
     {
@@ -89,10 +93,13 @@ void trt_emitter_patch(trt_emitter *e, const Screen *screen)
             three_digits(cell + BLUE_AT, (int)(px.z * 255));
         }
     }
+    return TRT_HOST_OK;
 }
 
-void trt_emitter_patch_rgb8(trt_emitter *e, const unsigned char *rgb)
+int trt_emitter_patch_rgb8(trt_emitter *e, const unsigned char *rgb)
 {
+    if (!e || !rgb)
+        return TRT_HOST_ERR_ARGUMENT;
     char *row_text = e->text + HOME_LEN;
     for (int row = 0; row < e->height; row++, row_text += (size_t)CELL_LEN * e->width + 1)
     {
@@ -104,15 +111,20 @@ void trt_emitter_patch_rgb8(trt_emitter *e, const unsigned char *rgb)
             three_digits(cell + BLUE_AT, rgb[2]);
         }
     }
+    return TRT_HOST_OK;
 }
 
 int trt_emitter_write(const trt_emitter *e, FILE *stream)
 {
+    if (!e || !stream)
+        return TRT_HOST_ERR_ARGUMENT;
     return fwrite(e->text, 1, e->size, stream) == e->size ? TRT_HOST_OK : TRT_HOST_ERR_OPEN;
 }
 
 int trt_draw_screen(const Screen *screen, FILE *stream)
 {
+    if (!screen || !screen->pixels || !stream)
+        return TRT_HOST_ERR_ARGUMENT;
     if (fputs(k_home, stream) < 0)
         return TRT_HOST_ERR_OPEN;
     for (int row = 0; row < screen->height; row++)

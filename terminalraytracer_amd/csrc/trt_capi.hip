@@ -24,8 +24,7 @@
 #define TRT_POINTGRID_CELLS 64
 #endif
 
-#include "trt_device.hpp"
-#include "trt_persistent.hpp"
+#include "trt_common.hpp"
 #include "trt_rounds.hpp"
 #include "trt_simple.hpp"
 
@@ -103,7 +102,6 @@ struct trt_context
     bool have_scene = false;
     trt::SceneView scene{};
     trt::CullView cull{};
-    int persistent_blocks_per_cu = 0; // occupancy of the production kernel for the current scene's LDS image
     DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb, d_axes, d_samples, d_samples_alt;
     DeviceBuffer<float> d_cull;
     // light-space candidate masks (trt_lightgrid.h) and the host copy of the primitives they were built from
@@ -128,7 +126,7 @@ struct trt_context
     int axes_w = -1, axes_h = -1;
     double axes_sw = 0.0, axes_sh = 0.0;
 
-    int kernel = 0; // 0 production (synchronous rounds), 1 reference-order, 2 per-lane state machine
+    int kernel = 0; // 0 production (persistent waves, synchronous rounds), 1 reference-order
     int rounds_blocks_per_cu = 0;
     size_t occupancy_for_lds = (size_t)-1;
     hipEvent_t ev_chunk[16]; // hand-over of framebuffer chunks to the host copy threads (trt_render_host)
@@ -136,16 +134,16 @@ struct trt_context
     hipStream_t copy_stream = nullptr;
     hipStream_t alt_stream = nullptr; // second render stream of trt_render_host: odd bands (their tails overlap the next band)
     hipEvent_t ev_fork = nullptr;
-    int units = 0;  // work units of the production kernel: 0 automatic, 1 pixels, 2 samples
     bool counters_enabled = false;
     unsigned long long last_trips = 0, last_phase2 = 0; // diagnostics of the counting kernel variant
 
-    hipEvent_t ev_start[kEventRing], ev_stop[kEventRing];
+    hipEvent_t ev_start[kEventRing], ev_mid[kEventRing], ev_stop[kEventRing]; // launch begins | render kernel done | reduction done
     long launches = 0;
 
     // skybox cache key of the default context
     const void *sky_faces[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int sky_dim = -1;
+    unsigned long long sky_stamp = 0; // content stamp of the faces (sampled texels): a free-and-reload at the same addresses is noticed
 };
 
 namespace
@@ -155,6 +153,24 @@ size_t scene_lds_bytes(const trt::SceneView &s)
 {
     return sizeof(double) * ((size_t)s.num_spheres * trt::kSphereDoubles + (size_t)s.num_dir * trt::kDirLightDoubles +
                              (size_t)s.num_point * trt::kPointLightDoubles);
+}
+
+// FNV-1a over 256 texels sampled at a fixed stride from every face: cheap enough for every frame of the drop-in call, and
+// a different image loaded into the same allocation (free + malloc of the same size often returns the same pointers) shows
+unsigned long long skybox_stamp(const Skybox *sky)
+{
+    unsigned long long h = 1469598103934665603ull;
+    const size_t face = (size_t)sky->dim * sky->dim, step = face / 256 ? face / 256 : 1;
+    for (int f = 0; f < 6; f++)
+        for (size_t i = 0; i < face; i += step)
+        {
+            const Color c = sky->colors[f][i];
+            h = (h ^ c.r) * 1099511628211ull;
+            h = (h ^ c.g) * 1099511628211ull;
+            h = (h ^ c.b) * 1099511628211ull;
+        }
+    const Color last = sky->colors[5][face - 1];
+    return (h ^ ((unsigned)last.r << 16 | (unsigned)last.g << 8 | last.b)) * 1099511628211ull;
 }
 
 int upload_skybox(trt_context *ctx, const Skybox *sky)
@@ -181,6 +197,7 @@ int upload_skybox(trt_context *ctx, const Skybox *sky)
     for (int f = 0; f < 6; f++)
         ctx->sky_faces[f] = sky->colors[f];
     ctx->sky_dim = dim;
+    ctx->sky_stamp = skybox_stamp(sky);
     return TRT_OK;
 }
 
@@ -344,19 +361,16 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
     v.num_dir = nd;
     v.num_point = np;
     memcpy(v.ground, &scene->ground, sizeof(Plane));
-    const size_t lds_need = std::max(scene_lds_bytes(v), trt::persistent_lds_bytes(v, 64));
+    const size_t lds_need = std::max(scene_lds_bytes(v), trt::rounds_lds_bytes(v, 64));
     if (lds_need > (size_t)ctx->lds_limit)
         return fail(TRT_ERR_CAPACITY, "scene needs %zu B of LDS staging, device offers %d", lds_need, ctx->lds_limit);
-    if (ctx->occupancy_for_lds != trt::persistent_lds_bytes(v, 64))
+    if (ctx->occupancy_for_lds != trt::rounds_lds_bytes(v, 64))
     { // occupancy depends on the scene only through the LDS image size: query once per size, not once per frame
         int blocks = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false, false>, trt::kPersistentBlock,
-                                                             trt::persistent_lds_bytes(v, 64)));
-        ctx->persistent_blocks_per_cu = std::max(blocks, 1);
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock,
-                                                             trt::persistent_lds_bytes(v, 64)));
+                                                             trt::rounds_lds_bytes(v, 64)));
         ctx->rounds_blocks_per_cu = std::max(blocks, 1);
-        ctx->occupancy_for_lds = trt::persistent_lds_bytes(v, 64);
+        ctx->occupancy_for_lds = trt::rounds_lds_bytes(v, 64);
     }
     return TRT_OK;
 }
@@ -475,6 +489,7 @@ static int init_context(trt_context *ctx)
     for (int i = 0; i < kEventRing; i++)
     {
         HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
+        HIP_TRY(hipEventCreate(&ctx->ev_mid[i]));
         HIP_TRY(hipEventCreate(&ctx->ev_stop[i]));
     }
     for (int i = 0; i < 16; i++)
@@ -489,10 +504,6 @@ static int init_context(trt_context *ctx)
     // dynamic LDS above the 64 KiB default needs the opt-in attribute
     (void)hipFuncSetAttribute((const void *)trt::render_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::probe_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
-    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
-    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
-    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
-    (void)hipFuncSetAttribute((const void *)trt::render_persistent_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     return TRT_OK;
@@ -509,6 +520,8 @@ extern "C" int trt_destroy(trt_context *ctx)
     {
         if (ctx->ev_start[i])
             (void)hipEventDestroy(ctx->ev_start[i]);
+        if (ctx->ev_mid[i])
+            (void)hipEventDestroy(ctx->ev_mid[i]);
         if (ctx->ev_stop[i])
             (void)hipEventDestroy(ctx->ev_stop[i]);
     }
@@ -627,17 +640,9 @@ extern "C" int trt_read_diagnostics(trt_context *ctx, unsigned long long *wave_l
 
 extern "C" int trt_set_kernel(trt_context *ctx, int which)
 {
-    if (!ctx || which < 0 || which > 2)
+    if (!ctx || which < 0 || which > 1)
         return fail(TRT_ERR_ARGUMENT, "kernel %d", which);
     ctx->kernel = which;
-    return TRT_OK;
-}
-
-extern "C" int trt_set_work_units(trt_context *ctx, int units)
-{
-    if (!ctx || units < 0 || units > 2)
-        return fail(TRT_ERR_ARGUMENT, "units %d", units);
-    ctx->units = units;
     return TRT_OK;
 }
 
@@ -699,14 +704,11 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
     ctx->last_phase2 = c[3];
     if (getenv("TRT_PRINT_STAMPS"))
     { // diagnostic builds only (-DTRT_STAMP=1): per-stage wave-cycle sums
-        static const char *const names_sm[8] = {"filter set-up", "phase 1 sweep", "phase 2 exact", "plane", "POST", "NORM", "FINISH", "loop edge"};
-        static const char *const names_rounds[24] = {"units+primary", "unit(next_dir)", "P set-up", "P sweep", "P exact tests", "P plane",
-                                                     "P post: hit", "P post: sky", "Sd look-up", "Sd set-up/load", "Sd sweep", "Sd exact tests",
-                                                     "Sd plane", "Sd tail", "Sp unit/look-up", "Sp set-up/load", "Sp sweep", "Sp exact tests",
-                                                     "Sp plane", "Sp tail", "lit accumulate", "END", "loop edge", "-"};
-        const bool rounds = ctx->kernel == 0 && ctx->units != 1;
-        const char *const *names = rounds ? names_rounds : names_sm;
-        const int slots = rounds ? 24 : 8;
+        static const char *const names[24] = {"units+primary", "unit(next_dir)", "P set-up", "P sweep", "P exact tests", "P plane",
+                                              "P post: hit", "P post: sky", "Sd look-up", "Sd set-up/load", "Sd sweep", "Sd exact tests",
+                                              "Sd plane", "Sd tail", "Sp unit/look-up", "Sp set-up/load", "Sp sweep", "Sp exact tests",
+                                              "Sp plane", "Sp tail", "lit accumulate", "END", "loop edge", "-"};
+        const int slots = 24;
         unsigned long long total = 0;
         for (int i = 0; i < slots; i++)
             total += c[4 + i];
@@ -790,50 +792,31 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         const unsigned grid = (unsigned)((pixels + block - 1) / block);
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
         hipLaunchKernelGGL(trt::render_simple_kernel, dim3(grid), dim3(block), lds, stream, ctx->scene, f);
+        HIP_TRY(hipEventRecord(ctx->ev_mid[slot], stream));
         HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
     }
     else
     {
         HIP_TRY(hipMemsetAsync(ctx->d_queue.ptr + 16 * lane_set, 0, 16 * sizeof(unsigned int), stream));
-        // production (kernel 0): synchronous rounds over sample units; pixel units on request go to the state machine
-        const bool rounds = ctx->kernel == 0 && ctx->units != 1;
-        const bool sample_units = rounds || ctx->units != 1;
-        const int blocks_per_cu = rounds ? ctx->rounds_blocks_per_cu : ctx->persistent_blocks_per_cu;
-        const long units = sample_units ? pixels * rays_per_pixel : pixels;
+        // production (kernel 0): persistent waves, synchronous rounds over SAMPLE units, then the ordered mean per pixel
+        const long units = pixels * rays_per_pixel;
         if ((unsigned long long)units >= 0x7fffffffull)
             return fail(TRT_ERR_ARGUMENT, "%ld work units exceed the 2^31 index range", units);
-        if (sample_units)
-        {
-            if (scratch.capacity < (size_t)units * 3)
-                HIP_TRY(hipStreamSynchronize(stream)); // a frame in flight may still use the old scratch
-            HIP_TRY(scratch.reserve((size_t)units * 3));
-            f.samples = scratch.ptr;
-            f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
-        }
-        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0), blocks_per_cu, units);
-        const size_t plds = trt::persistent_lds_bytes(ctx->scene, rays_per_pixel);
+        if (scratch.capacity < (size_t)units * 3)
+            HIP_TRY(hipStreamSynchronize(stream)); // a frame in flight may still use the old scratch
+        HIP_TRY(scratch.reserve((size_t)units * 3));
+        f.samples = scratch.ptr;
+        f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
+        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0),
+                                                                      ctx->rounds_blocks_per_cu, units);
+        const size_t plds = trt::rounds_lds_bytes(ctx->scene, rays_per_pixel);
         const dim3 grid(pl.grid), block(pl.block);
-        const bool count = ctx->counters_enabled;
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
-        if (rounds)
-        {
-            if (count)
-                hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
-            else
-                hipLaunchKernelGGL((trt::render_rounds_kernel<false>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
-        }
-        else if (sample_units)
-        {
-            if (count)
-                hipLaunchKernelGGL((trt::render_persistent_kernel<true, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f);
-            else
-                hipLaunchKernelGGL((trt::render_persistent_kernel<false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f);
-        }
-        else if (count)
-            hipLaunchKernelGGL((trt::render_persistent_kernel<true, false>), grid, block, plds, stream, ctx->scene, ctx->cull, f);
+        if (ctx->counters_enabled)
+            hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         else
-            hipLaunchKernelGGL((trt::render_persistent_kernel<false, false>), grid, block, plds, stream, ctx->scene, ctx->cull, f);
-        if (sample_units)
+            hipLaunchKernelGGL((trt::render_rounds_kernel<false>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
+        HIP_TRY(hipEventRecord(ctx->ev_mid[slot], stream));
         { // TRT.c:1063-1065: the mean over each pixel's samples, in sample order
             const long values = pixels * 3;
             hipLaunchKernelGGL(trt::reduce_samples_kernel, dim3((unsigned)((values + 255) / 256)), dim3(256), 0, stream,
@@ -1012,15 +995,32 @@ extern "C" int trt_kernel_times(trt_context *ctx, float *ms, int max)
     return (int)n;
 }
 
+extern "C" int trt_render_kernel_times(trt_context *ctx, float *render_ms, float *reduce_ms, int max)
+{
+    if (!ctx || !render_ms || max < 0)
+        return fail(TRT_ERR_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const long have = std::min<long>(ctx->launches, kEventRing);
+    const long n = std::min<long>(have, max);
+    for (long i = 0; i < n; i++)
+    {
+        const long launch = ctx->launches - n + i;
+        const int slot = (int)(launch % kEventRing);
+        HIP_TRY(hipEventElapsedTime(&render_ms[i], ctx->ev_start[slot], ctx->ev_mid[slot]));
+        if (reduce_ms)
+            HIP_TRY(hipEventElapsedTime(&reduce_ms[i], ctx->ev_mid[slot], ctx->ev_stop[slot]));
+    }
+    return (int)n;
+}
+
 extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *static_lds_bytes, int *max_blocks_per_cu,
                                int *compute_units)
 {
     if (!ctx)
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    const void *fn = ctx->kernel == 1   ? (const void *)trt::render_simple_kernel
-                     : ctx->kernel == 2 ? (const void *)trt::render_persistent_kernel<false, true>
-                                        : (const void *)trt::render_rounds_kernel<false>;
+    const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel : (const void *)trt::render_rounds_kernel<false>;
     hipFuncAttributes attr;
     HIP_TRY(hipFuncGetAttributes(&attr, fn));
     if (vgprs)
@@ -1032,11 +1032,9 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
     if (max_blocks_per_cu)
     {
         int blocks = 0;
-        const size_t lds = ctx->have_scene ? (ctx->kernel == 1 ? scene_lds_bytes(ctx->scene) : trt::persistent_lds_bytes(ctx->scene, 64)) : 0;
+        const size_t lds = ctx->have_scene ? (ctx->kernel == 1 ? scene_lds_bytes(ctx->scene) : trt::rounds_lds_bytes(ctx->scene, 64)) : 0;
         if (ctx->kernel == 1)
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_simple_kernel, 256, lds));
-        else if (ctx->kernel == 2)
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_persistent_kernel<false, true>, trt::kPersistentBlock, lds));
         else
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock, lds));
         *max_blocks_per_cu = blocks;
@@ -1206,7 +1204,8 @@ extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_l
         return rc;
     bool same_sky = ctx->sky_dim == scene->skybox.dim;
     for (int f = 0; f < 6 && same_sky; f++)
-        same_sky = ctx->sky_faces[f] == scene->skybox.colors[f];
+        same_sky = scene->skybox.colors[f] && ctx->sky_faces[f] == scene->skybox.colors[f];
+    same_sky = same_sky && scene->skybox.dim > 0 && ctx->sky_stamp == skybox_stamp(&scene->skybox);
     if (!same_sky)
     {
         rc = upload_skybox(ctx, &scene->skybox);

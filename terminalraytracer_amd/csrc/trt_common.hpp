@@ -1,0 +1,95 @@
+// trt_common.hpp -- what the kernels of the frame producer share: launch shape of the persistent grid, work-queue
+// constants, the LDS image size, the culling-table view, the diagnostic stamp macros and the two small streaming
+// kernels either side of the render kernel (ordered mean over a pixel's samples, RGB8 quantisation).
+#pragma once
+
+#include "trt_device.hpp"
+#include "trt_filter.h"
+
+namespace trt
+{
+
+constexpr int kPersistentBlock = 256;
+
+// TRT_STAMP=1: diagnostic build with s_memtime stamps between the stages of the main loop; per-stage wave-cycle
+// sums go to counters[4..] (read SHARES from it, never its run time: the stamps fence the schedule).
+#ifndef TRT_STAMP
+#define TRT_STAMP 0
+#endif
+#if TRT_STAMP
+#define TRT_STAMP_AT(slot)                                                                   \
+    do                                                                                       \
+    {                                                                                        \
+        unsigned long long now_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        stamp_sum[slot] += now_ - stamp_prev;                                                \
+        stamp_prev = now_;                                                                   \
+    } while (0)
+#else
+#define TRT_STAMP_AT(slot) \
+    do                     \
+    {                      \
+    } while (0)
+#endif
+
+// work units (single samples) fetched from the global queue per atomic; a returning atomic per request saturates
+// a single queue word (it cost 0.8 ms per frame before pooling)
+#ifndef TRT_QUEUE_CHUNK
+#define TRT_QUEUE_CHUNK 256
+#endif
+constexpr unsigned kQueueChunkSamples = TRT_QUEUE_CHUNK;
+static_assert(kQueueChunkSamples >= 64, "a chunk must hold the 64 units the lanes of a wave can ask for in one round");
+#ifndef TRT_CULL_GROUP
+#define TRT_CULL_GROUP 8
+#endif
+constexpr int kCullGroup = TRT_CULL_GROUP; // the culling table is padded to a multiple of this many entries
+
+struct PersistentLaunch
+{
+    unsigned grid, block;
+};
+
+inline PersistentLaunch persistent_launch_shape(int compute_units, int blocks_per_cu, long units)
+{
+    long want = (units + kPersistentBlock - 1) / kPersistentBlock;
+    long cap = (long)compute_units * (blocks_per_cu > 0 ? blocks_per_cu : 1);
+    return PersistentLaunch{(unsigned)(want < cap ? (want > 0 ? want : 1) : cap), (unsigned)kPersistentBlock};
+}
+
+// FP32 culling table of trt_filter.h on the device
+struct CullView
+{
+    const float *table; // padded to a multiple of kCullGroup entries of {Cx,Cy,Cz,kk}
+    int padded;
+    double c0x, c0y, c0z;
+    float cn, rm;
+};
+
+constexpr int kLdsCameraDoubles = 13;                       // basis x,y,z (9) eye (3) -screen_distance (1)
+constexpr int kDirGridDoubles = 10, kPointGridDoubles = 6;  // sizeof(trt_dirgrid) / 8, sizeof(trt_pointgrid) / 8 (asserted in trt_rounds.hpp)
+
+// TRT.c:1063-1066 for frames rendered with samples as work units: pixel = (((0 + s0) + s1) + ...) * (1/spp),
+// samples in index order.  The scratch is sample-major, samples[(k*pixels + pixel)*3 + channel], so that for every k
+// consecutive threads read consecutive doubles (a pure streaming kernel: spp*24 B read + 24 B written per pixel).
+__global__ __launch_bounds__(256) void reduce_samples_kernel(const double *samples, double *out, long values, int spp, double inv_spp)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; // one thread per colour channel of a pixel
+    if (i >= values)
+        return;
+    double mean = 0.0;
+    for (int k = 0; k < spp; k++)
+        mean += samples[(long)k * values + i];
+    out[i] = mean * inv_spp;
+}
+
+// (int)(c*255) per channel, TRT.c:1157-1163
+__global__ void quantize_kernel(const double *px, long n_values, unsigned char *rgb)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_values)
+        rgb[i] = (unsigned char)d2i(px[i] * 255);
+}
+
+} // namespace trt

@@ -1,0 +1,246 @@
+/*
+ * trt_raygrid.h -- candidate tables for PATH rays, and the list form of every candidate table (host + device, plain C).
+ *
+ * trace_ray (TRT.c:793-856) tests every sphere against every ray.  The production kernel used to find the few spheres
+ * a path ray can touch with a wave-uniform FP32 sweep over all N spheres (trt_filter.h: 9 VALU per sphere and ray).
+ * Path rays, however, come in FAMILIES whose members all pass (almost) through one point:
+ *
+ *   family 0          primary rays: they start at the eye (TRT.c:1010)
+ *   family 1          rays reflected by the ground plane whose parent ray started at the eye: mirror reflection about a
+ *                     plane maps the parent's line onto a line through the MIRROR IMAGE of the eye (TRT.c:1054-1056)
+ *   family 2 + i      rays that start on sphere i (reflected there): their line passes within r_i of its centre c_i
+ *   family 2 + N + i  rays reflected by the ground whose parent started on sphere i: within r_i of the mirror image of c_i
+ *
+ * A path ray's parent is the eye, a sphere or the ground, and a ray never goes from the ground to the ground, so these
+ * 2 + 2N families cover every path ray.  For a family F = (apex A, radius R): every ray (o, d), |d| = 1, whose LINE passes
+ * within R of A and whose origin is not more than R "behind" A, lambda = (o - A).d >= -R.  Claim: if such a ray hits a
+ * sphere (centre c, radius rho) at some t > 0, then with D = |c - A| and s = (rho + R)/D either s >= 0.7 or the angle
+ * between d and c - A is at most asin(s).  [With a = the line's point closest to A: |a - A| <= R, a - A is perpendicular
+ * to d, the hit point is a + mu d with mu = lambda + t > -R.  (c - A).d = (c - a).d >= mu - rho > -(R + rho), i.e.
+ * cos(angle) > -s; the distance from c to the parallel line through A is <= rho + R, i.e. sin(angle) <= s.  For s < 0.7
+ * the branch angle >= pi - asin(s) has cos <= -sqrt(1 - s^2) < -s: excluded.]  "Which spheres can the ray touch" thus
+ * depends on d alone, and is tabulated per family over a cube map of 6 x g x g direction cells exactly like the point
+ * lights' tables of trt_lightgrid.h (same cone records, same conservative cone / cell predicate, same FP32 look-up and
+ * growth constants); spheres with s >= 0.7 -- sphere i itself in its own families -- sit in every cell.
+ *
+ * Whether a ray BELONGS to the family it is looked up in is not taken on trust: trt_rayfamily_member() checks the two
+ * conditions above in FP64 for every ray (a cross product and two dot products), so the tables are conservative for any
+ * ray that passes, wherever it came from; a ray that fails (hit points far from the origin lose digits, degenerate
+ * normals, rays beyond the tables' range) falls back to the sweep.  Like the FP32 filter and the light tables, a table
+ * NEVER decides a hit: it only proposes the spheres that go to the EXACT FP64 test, in ascending index order.
+ * tests/test_raygrid.py checks "exact hit => in the list" on every path ray of real frames with this very code.
+ *
+ * Bounds.  rho^2 = r^2 + 2^-37 M^2 + ..., M >= |o - c| + r over the admissible origins (|o - A| <= rg), covers the
+ * reference's own discriminant rounding as in trt_lightgrid.h (1); the cones are built with R_build = r_chk (1 + 1e-9) +
+ * 1e-13 rg, which covers the rounding of the membership test itself (<= 8u |o - A| on the cross product) and
+ * |d.d - 1| <= 2^-40; the FP32 look-up of the cell from d is the point lights' (cones grown by 1e-5 rad, cells by 0.01
+ * cell, edge cells stretched past the face).
+ *
+ * LIST CELLS.  Every candidate table the kernel reads -- these and the light tables -- is stored as one 64-bit word per
+ * cell: byte 7 = count 0..7 and bytes 0..6 the sphere indices in ascending order; or byte 7 = 0x80, bits 32..47 = count,
+ * bits 0..31 = the offset of ceil(count/8) words of indices in a pool; or byte 7 = 0xFF: no list (pool exhausted), the
+ * ray falls back to the sweep.  One 8-byte load whatever N is (N <= 256), and the exact stage pops bytes.
+ */
+#ifndef TRT_RAYGRID_H
+#define TRT_RAYGRID_H
+
+#include "trt_lightgrid.h"
+
+typedef struct
+{
+    double a[3];   /* apex */
+    double r_chk;  /* membership: line within r_chk of the apex, origin not more than r_chk behind it */
+    double r_chk2; /* r_chk^2 */
+    double rg2;    /* admissible |o - apex|^2 */
+} trt_rayfamily;
+
+#define TRT_RAYFAMILY_DOUBLES 6
+
+/* maximum sphere count the list cells can index */
+#define TRT_LIST_MAX_SPHERES 256
+#define TRT_LIST_POOLED 0x80u
+#define TRT_LIST_NONE 0xFFu
+
+/* P mirrored about the plane through p0 with normal nrm (any length > 0): P - 2 ((P - p0).nrm / nrm.nrm) nrm */
+TRT_HD void trt_mirror_point(const double p[3], const double p0[3], const double nrm[3], double out[3])
+{
+    const double nn = nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2];
+    const double h = ((p[0] - p0[0]) * nrm[0] + (p[1] - p0[1]) * nrm[1] + (p[2] - p0[2]) * nrm[2]) / nn;
+    out[0] = p[0] - 2.0 * h * nrm[0];
+    out[1] = p[1] - 2.0 * h * nrm[1];
+    out[2] = p[2] - 2.0 * h * nrm[2];
+}
+
+/* Family with apex `apex` for rays that nominally start within `radius` of it (0: the eye; r_i: sphere i); `slack`
+ * absorbs the 1e-6 nudge of TRT.c:871-874 and the rounding of hit points. */
+TRT_HD void trt_rayfamily_init(trt_rayfamily *F, const double apex[3], double radius, double slack, const trt_cull_scene *cs)
+{
+    const double reach = (double)cs->cn + (double)cs->rm;
+    const double lc[3] = {apex[0] - cs->c0[0], apex[1] - cs->c0[1], apex[2] - cs->c0[2]};
+    const double away = __builtin_sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]);
+    const double rg = TRT_LIGHTGRID_RANGE * (reach + away) + 1.0;
+    const double mag = __builtin_fabs(apex[0]) + __builtin_fabs(apex[1]) + __builtin_fabs(apex[2]) + reach;
+    F->a[0] = apex[0], F->a[1] = apex[1], F->a[2] = apex[2];
+    F->r_chk = __builtin_fabs(radius) * (1.0 + 1e-6) + slack + 1e-9 * mag;
+    F->r_chk2 = F->r_chk * F->r_chk;
+    F->rg2 = rg * rg;
+}
+
+/* does the ray (o, d), d a unit vector up to 2^-40, belong to the family?  false for NaN */
+TRT_HD int trt_rayfamily_member(const trt_rayfamily *F, double ox, double oy, double oz, double dx, double dy, double dz)
+{
+    const double wx = ox - F->a[0], wy = oy - F->a[1], wz = oz - F->a[2];
+    const double cx = wy * dz - wz * dy, cy = wz * dx - wx * dz, cz = wx * dy - wy * dx;
+    const double c2 = cx * cx + cy * cy + cz * cz, lam = wx * dx + wy * dy + wz * dz, w2 = wx * wx + wy * wy + wz * wz;
+    return c2 <= F->r_chk2 && lam >= -F->r_chk && w2 <= F->rg2;
+}
+
+/* cell of direction (x, y, z) (any length > 0) in a cube map of 6 x g x g cells: the look-up of trt_pointgrid_cell */
+TRT_HD int trt_cubemap_cell(float x, float y, float z, float half_g, float g_max, int g)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
+    float major, pu, pv;
+    int face;
+    if (ax >= ay && ax >= az)
+        major = x, pu = y, pv = z, face = 0;
+    else if (ay >= az)
+        major = y, pu = z, pv = x, face = 2;
+    else
+        major = z, pu = x, pv = y, face = 4;
+    face += major < 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float inv = __builtin_amdgcn_rcpf(__builtin_fabsf(major));
+#else
+    const float inv = 1.0f / __builtin_fabsf(major);
+#endif
+    float cu = __builtin_fmaf(pu * inv, half_g, half_g), cv = __builtin_fmaf(pv * inv, half_g, half_g);
+    cu = __builtin_fminf(__builtin_fmaxf(cu, 0.0f), g_max);
+    cv = __builtin_fminf(__builtin_fmaxf(cv, 0.0f), g_max);
+    return (face * g + (int)cv) * g + (int)cu;
+}
+
+/* The cone of directions, seen from the family's apex, in which a member ray can hit sphere `s` (9-double record). */
+TRT_HD void trt_rayfamily_cone(const trt_rayfamily *F, const double *s, trt_pointgrid_cone *c)
+{
+    const double rg = __builtin_sqrt(F->rg2);
+    const double a[3] = {s[0] - F->a[0], s[1] - F->a[1], s[2] - F->a[2]};
+    const double D = __builtin_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    const double M = rg + D + __builtin_fabs(s[3]);
+    const double E = 0x1p-37 * M * M;
+    const double r_build = F->r_chk * (1.0 + 1e-9) + 1e-13 * rg;
+    const double rho = __builtin_sqrt(s[3] * s[3] + E) + 0x1p-45 * M + r_build;
+    const double sin_grow = 1.0000000000e-5, cos_grow = 0.99999999995; /* sin and cos of the 1e-5 rad the cones grow by */
+    c->everywhere = !(rho / D < 0.7) ? 1.0 : 0.0; /* also for D = 0 and NaN */
+    if (c->everywhere != 0.0)
+    {
+        c->a[0] = c->a[1] = c->a[2] = 0.0;
+        c->sin_a = 1.0, c->cos_a = 0.0;
+        return;
+    }
+    for (int k = 0; k < 3; k++)
+        c->a[k] = a[k] / D;
+    const double sn = rho / D, cn = __builtin_sqrt(1.0 - sn * sn);
+    const double sg = sn * cos_grow + cn * sin_grow + 1e-12, cg = cn * cos_grow - sn * sin_grow - 1e-12; /* half-angle + 1e-5 rad */
+    c->sin_a = sg < 1.0 ? sg : 1.0;
+    c->cos_a = cg > 0.0 ? cg : 0.0;
+    if (!(cg > 0.0))
+        c->everywhere = 1.0;
+}
+
+/* ---- list cells ---- */
+
+/* Pack the spheres marked in a cell's mask words (sphere j of word w at bit 63 - (j & 63)) into a list cell.  count <= 7:
+ * inline.  Otherwise ceil(count/8) pool words starting at *pool_next (the caller reserved them): returns the pooled
+ * cell and writes the indices; pool == NULL (no room): TRT_LIST_NONE. */
+TRT_HD int trt_list_count(const unsigned long long *mask, int words)
+{
+    int count = 0;
+    for (int w = 0; w < words; w++)
+        count += __builtin_popcountll(mask[w]);
+    return count;
+}
+
+TRT_HD unsigned long long trt_list_pack(const unsigned long long *mask, int words, int count, unsigned long long *pool, unsigned pool_offset)
+{
+    if (count <= 7)
+    {
+        unsigned long long cell = (unsigned long long)count << 56;
+        int k = 0;
+        for (int w = 0; w < words; w++)
+        {
+            unsigned long long m = mask[w];
+            while (m)
+            {
+                const int lead = __builtin_clzll(m);
+                m &= ~(0x8000000000000000ull >> lead);
+                cell |= (unsigned long long)(unsigned)(w * 64 + lead) << (8 * k++);
+            }
+        }
+        return cell;
+    }
+    if (!pool)
+        return (unsigned long long)TRT_LIST_NONE << 56;
+    unsigned long long cur = 0;
+    int k = 0;
+    for (int w = 0; w < words; w++)
+    {
+        unsigned long long m = mask[w];
+        while (m)
+        {
+            const int lead = __builtin_clzll(m);
+            m &= ~(0x8000000000000000ull >> lead);
+            cur |= (unsigned long long)(unsigned)(w * 64 + lead) << (8 * (k & 7));
+            if ((++k & 7) == 0)
+            {
+                pool[pool_offset + (unsigned)(k >> 3) - 1u] = cur;
+                cur = 0;
+            }
+        }
+    }
+    if (k & 7)
+        pool[pool_offset + (unsigned)(k >> 3)] = cur;
+    return ((unsigned long long)TRT_LIST_POOLED << 56) | ((unsigned long long)(unsigned)count << 32) | pool_offset;
+}
+
+/* number of entries of a list cell, -1 for TRT_LIST_NONE */
+TRT_HD int trt_list_entries(unsigned long long cell)
+{
+    const unsigned ctl = (unsigned)(cell >> 56);
+    if (ctl == TRT_LIST_NONE)
+        return -1;
+    return ctl & TRT_LIST_POOLED ? (int)((cell >> 32) & 0xffffu) : (int)ctl;
+}
+
+/* entry k of a list cell */
+TRT_HD int trt_list_entry(unsigned long long cell, const unsigned long long *pool, int k)
+{
+    if ((unsigned)(cell >> 56) & TRT_LIST_POOLED)
+        return (int)((pool[(unsigned)cell + (unsigned)(k >> 3)] >> (8 * (k & 7))) & 0xffu);
+    return (int)((cell >> (8 * k)) & 0xffu);
+}
+
+/* ---- host reference builder (tests; the library marks the cells on the device with the same predicates) ---- */
+static inline long trt_rayfamily_build(const double *spheres, int n, const trt_rayfamily *F, int g, unsigned long long *masks,
+                                       trt_pointgrid_cone *cones)
+{
+    const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
+    for (int i = 0; i < n; i++)
+        trt_rayfamily_cone(F, spheres + 9 * i, cones + i);
+    long bits = 0;
+    for (long cell = 0; cell < 6L * g * g; cell++)
+    {
+        unsigned long long *m = masks + cell * words;
+        for (int w = 0; w < words; w++)
+            m[w] = 0;
+        const int face = (int)(cell / ((long)g * g)), j = (int)((cell / g) % g), c = (int)(cell % g);
+        for (int i = 0; i < n; i++)
+            if (trt_pointgrid_reaches(cones + i, face, c, j, g))
+            {
+                trt_lightgrid_set(m, i);
+                bits++;
+            }
+    }
+    return bits;
+}
+
+#endif

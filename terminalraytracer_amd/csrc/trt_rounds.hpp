@@ -33,22 +33,11 @@
 #include "trt_device.hpp"
 #include "trt_filter.h"
 #include "trt_lightgrid.h"
-#include "trt_persistent.hpp"
+#include "trt_common.hpp"
 
 namespace trt
 {
 
-// TRT_SWEEP_MFMA: 0 (default) = phase 1 on the VALU (LDS-broadcast table, 9 / 5 VALU per sphere); 1 = phase 1 on the
-// matrix cores (sweep64_mfma below).  Both are exact; measured on MI355X at the north-star config, one frame in flight:
-//   VALU sweep, 125 VGPRs, 4 waves/SIMD                         3.30 ms
-//   MFMA sweep, 166 VGPRs, 3 waves/SIMD                         3.34 ms   (6 % faster than the VALU sweep at 3 waves)
-//   MFMA sweep forced to 128 VGPRs (140 B/lane of scratch)      3.75 ms
-// The 32 accumulator registers of a 32x32 tile pair cost the fourth wave, which is worth more than the offload.
-// 2 = 16x16x4 tiles for the path rays only (mfma16_sweep below; shadow rays keep their tables): exact as well, measured
-//   VALU sweep, 124 VGPRs 2.24 ms | 16x16x4 MFMA, 131 VGPRs, 3 waves/SIMD 2.51 ms | forced to 128 VGPRs 2.38 ms.
-#ifndef TRT_SWEEP_MFMA
-#define TRT_SWEEP_MFMA 0
-#endif
 
 // Light-space candidate masks (trt_lightgrid.h): per light one table of cells, each cell `words` 64-bit masks.
 struct GridView
@@ -66,11 +55,6 @@ struct LdsImage
 {
     const float4 *cull;  // culling table {Cx,Cy,Cz,kk}
     const float4 *cull_dir; // per directional light: {Cx,Cy,Cz,kk - (C.d)^2}, `padded` entries each
-    // MFMA A-operand images of the same tables, per 64-sphere chunk two 32-sphere blocks of 64 floats each:
-    // a_xy[(2*chunk + blk)*64 + lane] = lane < 32 ? Cx : Cy of sphere 64*chunk + 32*blk + lane%32;  a_zk likewise Cz : kk
-    const float *a_xy, *a_zk;
-    const float *a_zk_dir; // per directional light, 2*padded64 floats each: Cz : kk - (C.d)^2
-    int padded64;
     const double *cx, *cy, *cz, *r2;
     const double *mat;   // (n+2) x {colour, reflectivity, specularity}: spheres, ground even, ground odd
     const double *dir;   // per directional light: unit to-light (3), colour (3)
@@ -80,10 +64,20 @@ struct LdsImage
     const double *jit;   // jitter x[spp], y[spp]
     const trt_dirgrid *dirgrid;     // headers of the light-space tables (trt_lightgrid.h), per directional light
     const trt_pointgrid *pointgrid; // per point light
-    float *mfma16_wave;             // TRT_SWEEP_MFMA == 2: this wave's staging / exchange area
 };
 
-// same layout and size as trt_persistent.hpp (persistent_lds_bytes)
+// LDS image of a workgroup: culling table {Cx,Cy,Cz,kk} (4 floats per sphere, 16-B aligned, first) | cx[n] cy[n] cz[n] r2[n] |
+// mat[(n+2)*5] (spheres, ground even, ground odd) | dir lights: unit to-light(3) colour(3) | point lights: pos(3) colour(3)
+// intensity | byte/255.0 [256] | camera | jitter x[spp] y[spp] | one fixed-direction culling table per directional
+// light | headers of the light-space tables.  rounds_lds_bytes and stage_lds_image must agree.
+inline size_t rounds_lds_bytes(const SceneView &s, int spp)
+{
+    const size_t padded = ((size_t)s.num_spheres + kCullGroup - 1) / kCullGroup * kCullGroup;
+    return sizeof(double) * (padded * 2 + (size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * 6 +
+                             (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp + 1 /* 16-B alignment */ +
+                             (size_t)s.num_dir * padded * 2 + (size_t)s.num_dir * kDirGridDoubles + (size_t)s.num_point * kPointGridDoubles);
+}
+
 TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView &cull, const FrameView &f, const GridView &grids)
 {
     const int n = s.num_spheres, nd = s.num_dir, np = s.num_point;
@@ -133,27 +127,8 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
         const float dx = (float)l_dir[li * 6 + 0], dy = (float)l_dir[li * 6 + 1], dz = (float)l_dir[li * 6 + 2]; // = trt_filter_setup's d
         l_cull_dir[i] = float4{e.x, e.y, e.z, trt_filter_fixed_dir_kk(e.x, e.y, e.z, e.w, dx, dy, dz)};
     }
-    __syncthreads(); // the images below are built from l_cull_dir
-    // MFMA operand images behind the fixed-direction tables: per 32-sphere block 64 floats (lane l: k = l/32 of sphere l%32)
-    const int padded64 = (n + 63) / 64 * 64, image = 2 * padded64;
-    float *l_axy = (float *)(l_cull_dir + nd * cull.padded), *l_azk = l_axy + image, *l_azk_dir = l_azk + image;
-    for (int i = threadIdx.x; i < (TRT_SWEEP_MFMA == 1 ? (1 + nd) * image : 0); i += blockDim.x)
-    {
-        const int which = i / image, j = i - which * image; // which: 0 generic table, 1 + li fixed direction of light li
-        const int lane_ = j & 63, sphere = (j >> 6) * 32 + (lane_ & 31);
-        float4 e = float4{0.0f, 0.0f, 0.0f, TRT_CULL_PAD_KK};
-        if (sphere < cull.padded)
-            e = which == 0 ? l_cull[sphere] : l_cull_dir[(which - 1) * cull.padded + sphere];
-        if (which == 0)
-        {
-            l_axy[j] = lane_ < 32 ? e.x : e.y;
-            l_azk[j] = lane_ < 32 ? e.z : e.w;
-        }
-        else
-            l_azk_dir[(which - 1) * image + j] = lane_ < 32 ? e.z : e.w;
-    }
-    // headers of the light-space tables behind the MFMA images (whole doubles again: the images are 2*padded64 floats each)
-    double *l_dirgrid = (double *)(l_azk_dir + nd * image), *l_pointgrid = l_dirgrid + nd * kDirGridDoubles;
+    // headers of the light-space tables behind the fixed-direction tables (whole doubles again: 4 floats per entry)
+    double *l_dirgrid = (double *)(l_cull_dir + nd * cull.padded), *l_pointgrid = l_dirgrid + nd * kDirGridDoubles;
     if (grids.enabled)
     {
         for (int i = threadIdx.x; i < nd * kDirGridDoubles; i += blockDim.x)
@@ -162,9 +137,8 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
             l_pointgrid[i] = ((const double *)grids.point)[i];
     }
     __syncthreads();
-    return LdsImage{l_cull, l_cull_dir, l_axy, l_azk, l_azk_dir, padded64, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit,
-                    (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid,
-                    (float *)(l_pointgrid + np * kPointGridDoubles) + (threadIdx.x >> 6) * kMfma16WaveFloats};
+    return LdsImage{l_cull, l_cull_dir, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit,
+                    (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid};
 }
 
 struct Hit
@@ -174,152 +148,15 @@ struct Hit
     int i;     // -1: nothing; [0,n): sphere; n: ground
 };
 
-typedef float f16v __attribute__((ext_vector_type(16)));
-
-// v_permlane32_swap a, b:  a <- [a.lo32, b.lo32],  b <- [a.hi32, b.hi32]   (lo32 = lanes 0-31).  Through inline asm:
-// hipcc (ROCm 7.2) folds MFMAs fed by the two results of __builtin_amdgcn_permlane32_swap into one (tools/mfma_probe).
-// The s_nops cover the data hazards around it (VALU result -> permlane read, permlane result -> MFMA/VALU read):
-// the compiler's hazard recogniser cannot look inside the asm statement (cdna_hip_programming.md 5.7).
-TRT_DEV void lane_swap32(float &a, float &b)
-{
-    asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(a), "+v"(b));
-}
-
-// Phase 1 for one chunk of 64 spheres and the 64 rays of the wave, on the MATRIX cores.
-// The culling test is a small dense contraction: for sphere row j and ray column i (K = 4)
-//     cd[j][i] = (Cx,Cy,Cz,kk) . (dx,dy,dz, 0)              cw[j][i] = (Cx,Cy,Cz,kk) . (wx,wy,wz,-1) - thr_i
-// and the verdict is the sign of fma(cd,cd,cw) (trt_filter.h).  v_mfma_f32_32x32x2_f32 evaluates exactly that FMA chain
-// (k = 0..3, FP32, checked bit for bit against fmaf by tools/mfma_probe), on a pipe of its own, so the VALU is left with
-// one FMA and one v_alignbit per (ray, sphere) -- v_alignbit alone for a fixed direction, whose cd^2 is in the table.
-// Tiles: 2 blocks of 32 spheres x 2 blocks of 32 rays.  A operand of a sphere block: lane l holds A[l%32][k = l/32];
-// B operand of a ray block: lane l holds B[k = l/32][l%32], made from the per-lane ray constants with one
-// v_permlane32_swap per pair; D: lane l holds ray l%32 and, in register v, sphere row (v/4)*8 + (l/32)*4 + v%4.
-// Returns, for THIS lane's ray, two 32-bit words (rows held by lanes < 32 / >= 32): bit 31-p of word h set = candidate
-// sphere 32*(p>>4) + ((p&15)>>2)*8 + 4*h + (p&3) of the chunk.
-template <bool FIXED>
-TRT_DEV void sweep64_mfma(const float *a_xy, const float *a_zk, int lane, const trt_ray_filter &f, unsigned &half0, unsigned &half1)
-{
-    const float axy[2] = {a_xy[lane], a_xy[64 + lane]}, azk[2] = {a_zk[lane], a_zk[64 + lane]};
-    float wxy[2] = {f.wx, f.wy}, wz1[2] = {f.wz, -1.0f}, thr[2] = {f.neg_thr, f.neg_thr};
-    lane_swap32(wxy[0], wxy[1]);
-    lane_swap32(wz1[0], wz1[1]);
-    lane_swap32(thr[0], thr[1]); // thr[r] = -thr of ray l%32 + 32r in every lane
-    float dxy[2] = {f.dx, f.dy}, dz0[2] = {f.dz, 0.0f};
-    if (!FIXED)
-    {
-        lane_swap32(dxy[0], dxy[1]);
-        lane_swap32(dz0[0], dz0[1]);
-    }
-    float word[2];
-#pragma unroll
-    for (int r = 0; r < 2; r++)
-    {
-        unsigned bits = ~0u;
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-        {
-            f16v cw;
-#pragma unroll
-            for (int v = 0; v < 16; v++)
-                cw[v] = thr[r];
-            cw = __builtin_amdgcn_mfma_f32_32x32x2f32(axy[s], wxy[r], cw, 0, 0, 0);
-            cw = __builtin_amdgcn_mfma_f32_32x32x2f32(azk[s], wz1[r], cw, 0, 0, 0);
-            if (!FIXED)
-            {
-                f16v cd = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                cd = __builtin_amdgcn_mfma_f32_32x32x2f32(axy[s], dxy[r], cd, 0, 0, 0);
-                cd = __builtin_amdgcn_mfma_f32_32x32x2f32(azk[s], dz0[r], cd, 0, 0, 0);
-#pragma unroll
-                for (int v = 0; v < 16; v++)
-                {
-                    const float m = __builtin_fmaf(cd[v], cd[v], cw[v]);
-                    bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(unsigned, m), 31);
-                }
-            }
-            else
-            {
-#pragma unroll
-                for (int v = 0; v < 16; v++)
-                {
-                    const float m = cw[v]; // NB: __builtin_bit_cast applied to the element lvalue cw[v] itself reads element 0
-                    bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(unsigned, m), 31);
-                }
-            }
-        }
-        word[r] = __builtin_bit_cast(float, ~bits); // set = candidate
-    }
-    lane_swap32(word[0], word[1]); // both halves of the rows of this lane's own ray
-    half0 = __builtin_bit_cast(unsigned, word[0]);
-    half1 = __builtin_bit_cast(unsigned, word[1]);
-}
-
-#if TRT_SWEEP_MFMA == 2
-typedef float f4v __attribute__((ext_vector_type(4)));
-
-// Phase 1 of a PATH ray on the matrix cores, 16x16x4 tiles (experiment).  v_mfma_f32_16x16x4_f32 is the FMA
-// chain over k = 0..3 starting from C (tools/mfma16_probe: bit-identical), i.e. the order of trt_filter_sign_mfma.
-// Rows = spheres (A straight from the {Cx,Cy,Cz,kk} table: lane l reads component l/16 of sphere l%16 of the tile),
-// columns = rays (B from the rays' vectors staged in LDS once per trace: lane l reads component l/16 of ray 16t + l%16),
-// D: lane l, register v = sphere 4*(l/16) + v of the tile, ray 16t + l%16.  Each lane packs the sign bits it holds into
-// their final positions of the ray's candidate word; the ray's own lane ORs the four partial words via LDS.
-TRT_DEV void mfma16_stage_ray(float *wave, int lane, const trt_ray_filter &f)
-{
-    float *r = wave + lane * kMfma16RayFloats;
-    r[0] = f.wx, r[1] = f.wy, r[2] = f.wz, r[3] = -1.0f;
-    r[4] = f.dx, r[5] = f.dy, r[6] = f.dz, r[7] = 0.0f;
-    r[8] = f.neg_thr;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-// bit 63-j set = sphere j of the chunk is REJECTED for this lane's ray
-TRT_DEV unsigned long long mfma16_sweep(const float4 *table, float *wave, int lane)
-{
-    const int q = lane >> 4, c = lane & 15;
-    float a[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-        a[s] = ((const float *)table)[(16 * s + c) * 4 + q];
-    unsigned long long *xch = (unsigned long long *)(wave + 64 * kMfma16RayFloats);
-    const unsigned shift = 12u - 4u * (unsigned)q;
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-    {
-        const float *ray = wave + (16 * t + c) * kMfma16RayFloats;
-        const float bw = ray[q], bd = ray[4 + q], thr = ray[8];
-        unsigned word[2] = {0u, 0u};
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-        {
-            f4v cw = {thr, thr, thr, thr}, cd = {0.0f, 0.0f, 0.0f, 0.0f};
-            cw = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw, cw, 0, 0, 0);
-            cd = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bd, cd, 0, 0, 0);
-            unsigned w = word[s >> 1];
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-            {
-                const float m = __builtin_fmaf(cd[v], cd[v], cw[v]);
-                w = __builtin_amdgcn_alignbit(w, __builtin_bit_cast(unsigned, m), 31);
-            }
-            word[s >> 1] = (s & 1) ? w : w << 12;
-        }
-        xch[lane * 4 + t] = ((unsigned long long)(word[0] << shift) << 32) | (word[1] << shift);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int own = lane >> 4;
-    const unsigned long long rejected = xch[c * 4 + own] | xch[(c + 16) * 4 + own] | xch[(c + 32) * 4 + own] | xch[(c + 48) * 4 + own];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the next chunk overwrites the exchange buffer
-    return rejected;
-}
-#endif
 
 // Closest hit of TRT.c:793-856 for the lanes with `active`.  ANY_HIT: the caller only asks whether anything
 // is hit (directional-light shadow ray, TRT.c:908), so a lane stops at its first hit and the ground is skipped
-// once a sphere was found.  `a_zk_fixed` != nullptr: all rays share the direction that table was built for.
+// once a sphere was found.  `fixed` != nullptr: all rays share the direction that culling table was built for.
 // `use_masks` (wave-uniform): the candidates come from this lane's cell of a light-space table (`masks`, one word per
 // chunk of 64 spheres) instead of the sweep.
 template <bool ANY_HIT>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
-                  int lane, const float4 *fixed = nullptr, const float *a_zk_fixed = nullptr, bool use_masks = false,
+                  int lane, const float4 *fixed = nullptr, bool use_masks = false,
                   const unsigned long long *masks = nullptr
 #if TRT_STAMP
                   ,
@@ -338,74 +175,15 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
 #endif
     (void)lane;
     (void)fixed;
-    (void)a_zk_fixed;
     Hit best;
     best.d2 = __builtin_inf();
     best.p = o;
     best.i = -1;
     const double a = dot(d, d);
     trt_ray_filter flt;
-    if (TRT_SWEEP_MFMA == 1 || !use_masks)
+    if (!use_masks)
         trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
-#if TRT_SWEEP_MFMA == 2
-    const bool matrix_sweep = !use_masks && !(ANY_HIT && fixed); // the general sweep; a fixed-direction fall-back stays on the VALU
-    if (matrix_sweep)
-        mfma16_stage_ray(L.mfma16_wave, lane, flt);
-#endif
 
-#if TRT_SWEEP_MFMA == 1
-    for (int base = 0; base < L.padded64; base += 64)
-    {
-        // phase 1 on the matrix cores (all 64 lanes take part: the tiles hold every lane's column)
-        unsigned half[2];
-        if (ANY_HIT && a_zk_fixed)
-            sweep64_mfma<true>(L.a_xy + 2 * base, a_zk_fixed + 2 * base, lane, flt, half[0], half[1]);
-        else
-            sweep64_mfma<false>(L.a_xy + 2 * base, L.a_zk + 2 * base, lane, flt, half[0], half[1]);
-        if (!flt.ok)
-            half[0] = half[1] = ~0u; // degenerate ray: every sphere of the chunk goes to the exact test
-        if (!active)
-            half[0] = half[1] = 0u;
-        // phase 2: exact FP64 tests of this lane's candidates.  The words are not in sphere order, so the tie rule of
-        // TRT.c:816 (strict '<': the lowest index wins among equal distances) is applied explicitly.
-        while (__any((half[0] | half[1]) != 0))
-        {
-            phase2_rounds++;
-            if ((half[0] | half[1]) != 0)
-            {
-                const int h = half[0] != 0 ? 0 : 1;
-                const int p = __builtin_clz(half[h]);
-                half[h] &= ~(0x80000000u >> p);
-                const int i = base + ((p >> 4) << 5) + (((p & 15) >> 2) << 3) + (h << 2) + (p & 3);
-                if (i < n)
-                {
-                    const d3 c = d3{L.cx[i], L.cy[i], L.cz[i]};
-                    const d3 oc = sub(o, c);
-                    const double b = 2.0 * dot(oc, d);
-                    const double cc = dot(oc, oc) - L.r2[i];
-                    const double disc = b * b - 4.0 * a * cc;
-                    if (!(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
-                    {
-                        const double t0 = (-b - sqrt_exact(disc)) / (2.0 * a);
-                        if (t0 > 0.0)
-                        {
-                            const d3 pt = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
-                            const double d2 = dist2(o, pt);
-                            if (d2 < best.d2 || (d2 == best.d2 && i < best.i))
-                            {
-                                best.d2 = d2;
-                                best.p = pt;
-                                best.i = i;
-                            }
-                            if (ANY_HIT)
-                                half[0] = half[1] = 0u;
-                        }
-                    }
-                }
-            }
-        }
-    }
-#else
     for (int base = 0; base < cull.padded; base += 64)
     {
         // phase 1: wave-uniform sweep; each verdict is a sign bit shifted into a per-lane word by v_alignbit,
@@ -424,17 +202,6 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         {
         TRT_TRACE_STAMP(0);
         unsigned word[2];
-#if TRT_SWEEP_MFMA == 2
-        if (matrix_sweep)
-        {
-            const unsigned long long rejected = mfma16_sweep(L.cull + base, L.mfma16_wave, lane);
-            word[0] = ~(unsigned)(rejected >> 32), word[1] = ~(unsigned)rejected;
-            const int c0 = chunk < 32 ? chunk : 32, c1 = chunk - c0; // entries past the table's end are not spheres
-            word[0] &= c0 == 32 ? ~0u : ~(0xffffffffu >> c0);
-            word[1] &= c1 == 32 ? ~0u : (c1 == 0 ? 0u : ~(0xffffffffu >> c1));
-        }
-        else
-#endif
 #pragma unroll
         for (int h = 0; h < 2; h++)
         {
@@ -502,7 +269,6 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
             }
         }
     }
-#endif
     TRT_TRACE_STAMP(2); // exact tests
     // ground plane (TRT.c:831-853)
     if (active && !(ANY_HIT && best.i >= 0))
@@ -637,7 +403,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             n_path++;
         TRT_STAMP_AT(1); // unit(next_dir)
 #if TRT_STAMP
-        const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2, lane, nullptr, nullptr, false, nullptr, stamp_sum, &stamp_prev, 2);
+        const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2, lane, nullptr, false, nullptr, stamp_sum, &stamp_prev, 2);
 #else
         const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2, lane);
 #endif
@@ -704,10 +470,10 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                     TRT_STAMP_AT(8); // look-up
 #if TRT_STAMP
                     const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, L.cull_dir + li * cull.padded,
-                                               L.a_zk_dir + li * 2 * L.padded64, use_masks, cell, stamp_sum, &stamp_prev, 9);
+                                               use_masks, cell, stamp_sum, &stamp_prev, 9);
 #else
                     const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, L.cull_dir + li * cull.padded,
-                                               L.a_zk_dir + li * 2 * L.padded64, use_masks, cell);
+                                               use_masks, cell);
 #endif
                     is_lit = sh.i < 0;
                     factor = min1(dot(h_normal, sd));
@@ -734,9 +500,9 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                     }
                     TRT_STAMP_AT(14); // unit(to_light), strength, look-up
 #if TRT_STAMP
-                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, nullptr, nullptr, use_masks, cell, stamp_sum, &stamp_prev, 15);
+                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, nullptr, use_masks, cell, stamp_sum, &stamp_prev, 15);
 #else
-                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, nullptr, nullptr, use_masks, cell);
+                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, nullptr, use_masks, cell);
 #endif
                     is_lit = sh.i < 0;
                     // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the

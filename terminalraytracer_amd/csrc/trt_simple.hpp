@@ -1,10 +1,10 @@
 // trt_simple.hpp -- reference-order kernel: one lane per pixel, samples and bounces looped in the
 // lane exactly as project_scene does (TRT.c:966-1069), every sphere tested exactly, no culling.
-// It is the on-device parity anchor for the production kernel (trt_persistent.hpp) and the
-// implementation behind trt_probe_rays.  Scene records are staged into LDS once per workgroup.
+// It is the on-device parity anchor for the production kernel (trt_rounds.hpp), an independent implementation of the
+// same path, and the code behind trt_probe_rays(..., production = 0).  Scene records are staged into LDS once per workgroup.
 #pragma once
 
-#include "trt_device.hpp"
+#include "trt_common.hpp"
 
 namespace trt
 {
@@ -257,14 +257,6 @@ __global__ void unit_selftest_kernel(const double *v, long n, double *fast, doub
         fast[4 * i] = f.x, fast[4 * i + 1] = f.y, fast[4 * i + 2] = f.z, fast[4 * i + 3] = sqrt_exact(v[4 * i + 3]);
         reference[4 * i] = r.x, reference[4 * i + 1] = r.y, reference[4 * i + 2] = r.z, reference[4 * i + 3] = __builtin_sqrt(v[4 * i + 3]);
     }
-}
-
-// (int)(c*255) per channel, TRT.c:1157-1163
-__global__ void quantize_kernel(const double *px, long n_values, unsigned char *rgb)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_values)
-        rgb[i] = (unsigned char)d2i(px[i] * 255);
 }
 
 } // namespace trt

@@ -62,11 +62,11 @@ SYMBOLS = {
     "trt_render_host": (_I, [_VP, C.POINTER(L.Camera), C.POINTER(RowSet), _I, _I, _VP]),
     "trt_synchronize": (_I, [_VP]),
     "trt_kernel_times": (_I, [_VP, C.POINTER(C.c_float), _I]),
+    "trt_render_kernel_times": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), _I]),
     "trt_enable_counters": (_I, [_VP, _I]),
     "trt_read_counters": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "trt_read_diagnostics": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "trt_set_kernel": (_I, [_VP, _I]),
-    "trt_set_work_units": (_I, [_VP, _I]),
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
     "trt_reserve_cus": (_I, [_VP, _I]),
     "trt_get_stream": (_I, [_VP, C.POINTER(C.c_void_p)]),
@@ -115,7 +115,7 @@ def camera_struct(camera_array):
 class Context:
     """One renderer on one GPU (trt_context)."""
 
-    PRODUCTION, REFERENCE_ORDER, STATE_MACHINE = 0, 1, 2
+    PRODUCTION, REFERENCE_ORDER = 0, 1
 
     def __init__(self, device=0):
         self._h = _VP()
@@ -148,10 +148,6 @@ class Context:
 
     def set_kernel(self, which):
         _check(lib().trt_set_kernel(self._h, which))
-
-    def set_work_units(self, units):
-        """0 automatic, 1 pixels, 2 samples (trt_set_work_units)"""
-        _check(lib().trt_set_work_units(self._h, units))
 
     def reserve_cus(self, reserved):
         """keep `reserved` compute units free of this context's kernels (trt_reserve_cus)"""
@@ -207,6 +203,14 @@ class Context:
         if n < 0:
             _check(n)
         return [buf[i] for i in range(n)]
+
+    def render_kernel_times(self, max_count=256):
+        """(render_ms[], reduce_ms[]) of the most recent launches: the render kernel alone and the ordered mean"""
+        a, b = (C.c_float * max_count)(), (C.c_float * max_count)()
+        n = lib().trt_render_kernel_times(self._h, a, b, max_count)
+        if n < 0:
+            _check(n)
+        return [a[i] for i in range(n)], [b[i] for i in range(n)]
 
     def enable_counters(self, on=True):
         _check(lib().trt_enable_counters(self._h, 1 if on else 0))

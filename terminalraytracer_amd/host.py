@@ -25,10 +25,11 @@ HOST_SYMBOLS = {
     "trt_emitter_destroy": (None, [_VP]),
     "trt_emitter_buffer": (_VP, [_VP]),
     "trt_emitter_size": (C.c_size_t, [_VP]),
-    "trt_emitter_patch": (None, [_VP, C.POINTER(L.Screen)]),
-    "trt_emitter_patch_rgb8": (None, [_VP, _VP]),
+    "trt_emitter_patch": (C.c_int, [_VP, C.POINTER(L.Screen)]),
+    "trt_emitter_patch_rgb8": (C.c_int, [_VP, _VP]),
     "trt_emitter_write": (_I, [_VP, _VP]),
     "trt_draw_screen": (_I, [C.POINTER(L.Screen), _VP]),
+    "trt_fnv1a64": (C.c_ulonglong, [_VP, C.c_size_t]),
 }
 _bound = False
 
@@ -81,11 +82,15 @@ class Emitter:
         scr = L.Screen()
         scr.pixels = px.ctypes.data_as(C.POINTER(L.Vector))
         scr.width, scr.height = self.width, self.height
-        lib().trt_emitter_patch(self._h, C.byref(scr))
+        rc = lib().trt_emitter_patch(self._h, C.byref(scr))
+        if rc != 0:
+            raise ValueError(f"trt_emitter_patch failed with {rc}")
 
     def patch_rgb8(self, rgb):
         a = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(self.height, self.width, 3)
-        lib().trt_emitter_patch_rgb8(self._h, a.ctypes.data)
+        rc = lib().trt_emitter_patch_rgb8(self._h, a.ctypes.data)
+        if rc != 0:
+            raise ValueError(f"trt_emitter_patch_rgb8 failed with {rc}")
 
     def bytes(self):
         n = lib().trt_emitter_size(self._h)
@@ -101,3 +106,9 @@ class Emitter:
             self.close()
         except Exception:
             pass
+
+
+def fnv1a64(buf):
+    """FNV-1a-64 of an array's bytes as 16 hex digits: the fingerprint the golden frames are recorded with (trt_fnv1a64)."""
+    a = np.ascontiguousarray(buf)
+    return f"{lib().trt_fnv1a64(a.ctypes.data, a.nbytes):016x}"

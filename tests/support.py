@@ -143,3 +143,17 @@ def bench_camera(width, height, t=1.0):
     cam = d["camera"][i].copy()
     cam[13] = 5 * float(width) / float(height)
     return cam
+
+
+@functools.lru_cache(maxsize=None)
+def golden_full():
+    """Full-size frames hashed by the genuine reference (tests/golden/make_golden_full.py): BASELINE configs 2-5 at the
+    sizes the bench and the GPU tests render them, and frames with 1024^2 / 2048^2 cubemaps."""
+    with open(os.path.join(GOLDEN, "golden_full.json")) as fh:
+        return {c["name"]: c for c in json.load(fh)["cases"]}
+
+
+def full_scene(case):
+    """The scene of a golden_full case: SYNTH-v0 spheres, procedural cubemap, the reference's stored camera."""
+    return S.synth_scene(case["spheres"], S.synth_sky(case["sky_dim"], seed=case["sky_seed"]),
+                         np.array(case["camera"], dtype=np.float64), seed=case["scene_seed"])
