@@ -146,6 +146,26 @@ int trt_set_kernel(trt_context *ctx, int which);
  * bit-identical either way.  Defaults: 128 and 64; environment TRT_LIGHTGRID="d,p" overrides the defaults. */
 int trt_set_light_grids(trt_context *ctx, int directional_cells, int point_cells);
 
+/* Candidate tables of the PATH rays (csrc/trt_raygrid.h): path rays come in families that pass (nearly) through one point --
+ * the eye, its mirror image in the ground, a sphere, a sphere's mirror image -- and each family has a cube map of
+ * 6 * cells^2 direction cells listing the spheres its rays can touch; a path ray reads ONE cell instead of sweeping all
+ * spheres (TRT.c:805-828 tests every sphere).  eye_cells: per face side for the two families of the eye (rebuilt on the GPU
+ * when the eye moves), sphere_cells: for the 2N families of the spheres (rebuilt when spheres or ground change).
+ * 0, 0 turns them off (every path ray sweeps); frames are bit-identical either way.  Defaults 64 and 16; environment
+ * TRT_PATHGRID="e,s" overrides the defaults.  Scenes with more than 256 spheres render without any candidate table. */
+int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_cells);
+
+/* Copy the path rays' tables to the host (tests: the device-built lists must equal the host reference builder's): list
+ * cells (2*6*eye_cells^2, then 2N*6*sphere_cells^2) and the pool of long lists, as built for `camera`'s eye.
+ * info: {enabled, eye_cells, sphere_cells, N, cells, pool words used by the scene's tables, by the eye's, pool capacity}.
+ * Returns the number of cells copied, 0 when the tables are off, or a negative TRT_ERR_*. */
+long trt_read_path_tables(trt_context *ctx, const Camera *camera, unsigned long long *cells, size_t capacity_cells,
+                          unsigned long long *pool, size_t capacity_pool, long info[8]);
+
+/* After trt_read_counters: the number of wave-level traces of the last counted frame in which some ray failed its table's
+ * membership / range test and the whole wave swept the culling table instead (the slow path). */
+int trt_read_sweep_fallbacks(trt_context *ctx, unsigned long long *swept_traces);
+
 /* Copy one light's table to the host (tests: the device-built table must equal the host reference builder's).
  * point_light: 0 = directional light `index`, 1 = point light `index`.  Returns the number of 64-bit words copied
  * (cells * ceil(N/64)), 0 when the tables are off, or a negative TRT_ERR_*. */
@@ -170,6 +190,15 @@ int trt_selftest_unit(trt_context *ctx, const double *xyzw, size_t n, double *fa
  * the lighting of TRT.c:894 for hits. */
 int trt_probe_rays(trt_context *ctx, const Ray *rays, size_t n, int *obj, double *point, double *normal,
                    double *material, double *lit);
+
+/* The same probe through the PRODUCTION kernel's stages (csrc/trt_rounds.hpp: candidate tables, fall-back sweep, exact
+ * tests, surface record, lighting), so that trace_ray (TRT.c:793), ray_intersects_sphere/plane (:638, :677),
+ * get_skybox_color (:700) and apply_lighting (:894) are each checked on the code that ships.  families[i] = the family of
+ * the path-ray tables ray i is looked up in (0 eye, 1 mirror eye, 2 + s sphere s, 2 + N + s mirror sphere s; negative or
+ * families == NULL: none, the ray's wave sweeps); a ray that is not a member of the family named falls back by itself.
+ * camera: its origin is the eye the tables of families 0 and 1 are built for. */
+int trt_probe_rays_production(trt_context *ctx, const Camera *camera, const Ray *rays, const int *families, size_t n, int *obj,
+                              double *point, double *normal, double *material, double *lit);
 
 const char *trt_last_error(void);
 const char *trt_version(void);

@@ -24,6 +24,15 @@
 #define TRT_POINTGRID_CELLS 64
 #endif
 
+// candidate tables of the path rays' families (trt_raygrid.h): cells per side of a cube-map face for the two families of
+// the eye / for the 2N families of the spheres
+#ifndef TRT_PATHGRID_EYE
+#define TRT_PATHGRID_EYE 64
+#endif
+#ifndef TRT_PATHGRID_SPHERE
+#define TRT_PATHGRID_SPHERE 16
+#endif
+
 #include "trt_common.hpp"
 #include "trt_rounds.hpp"
 #include "trt_simple.hpp"
@@ -112,6 +121,17 @@ struct trt_context
     DeviceBuffer<trt_pointgrid_cone> d_cones; // per point light and sphere
     trt::GridView grids{};
     int dirgrid_cells = TRT_DIRGRID_CELLS, pointgrid_cells = TRT_POINTGRID_CELLS; // per side; 0 = no tables (sweep only)
+    // the tables as LIST CELLS (trt_raygrid.h), which is what the kernel reads: one 64-bit word per cell, long lists in d_pool
+    DeviceBuffer<unsigned long long> d_dir_lists, d_point_lists, d_path_lists, d_pool;
+    DeviceBuffer<unsigned int> d_pool_used;    // [0] words taken by the scene's tables, [16] by the eye's (a cache line apart)
+    DeviceBuffer<trt_rayfamily> d_families;    // the 2N families of the spheres, for the marking kernel
+    DeviceBuffer<double> d_sphere_fam;         // per sphere {mirror centre, r_chk}: what the render kernel keeps in LDS
+    int path_g_eye = TRT_PATHGRID_EYE, path_g_sph = TRT_PATHGRID_SPHERE; // 0 = no path tables (every path ray sweeps)
+    int path_built_for[2] = {-1, -1};
+    size_t pool_scene_words = 0, pool_eye_words = 0; // capacities of the two parts of d_pool
+    trt_cull_scene cull_scene{};                      // of the spheres the tables were built from
+    double eye_built[3] = {0.0, 0.0, 0.0}, ground_built[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    bool eye_tables_valid = false;
     std::vector<double> h_spheres, h_dir, h_point; // what the tables on the device were built from
     int grids_built_for[2] = {-1, -1};
     DeviceBuffer<uint32_t> d_sky;
@@ -135,7 +155,7 @@ struct trt_context
     hipStream_t alt_stream = nullptr; // second render stream of trt_render_host: odd bands (their tails overlap the next band)
     hipEvent_t ev_fork = nullptr;
     bool counters_enabled = false;
-    unsigned long long last_trips = 0, last_phase2 = 0; // diagnostics of the counting kernel variant
+    unsigned long long last_trips = 0, last_phase2 = 0, last_swept = 0; // diagnostics of the counting kernel variant
 
     hipEvent_t ev_start[kEventRing], ev_mid[kEventRing], ev_stop[kEventRing]; // launch begins | render kernel done | reduction done
     long launches = 0;
@@ -235,6 +255,53 @@ __global__ void build_pointgrid_kernel(const trt_pointgrid_cone *cones, int n, i
     }
 }
 
+// Mask words of a table -> list cells (trt_raygrid.h).  Lists longer than seven entries take words from the pool; when
+// the pool's part is exhausted the cell says TRT_LIST_NONE and its rays sweep.
+__device__ unsigned long long pack_cell(const unsigned long long *mask, int words, unsigned long long *pool, unsigned *pool_used, unsigned pool_limit)
+{
+    const int count = trt_list_count(mask, words);
+    if (count <= 7)
+        return trt_list_pack(mask, words, count, nullptr, 0u);
+    const unsigned need = (unsigned)(count + 7) / 8u;
+    const unsigned at = atomicAdd(pool_used, need);
+    if (at + need > pool_limit || at + need < at)
+        return (unsigned long long)TRT_LIST_NONE << 56;
+    return trt_list_pack(mask, words, count, pool, at);
+}
+
+__global__ void pack_lists_kernel(const unsigned long long *masks, long cells, int words, unsigned long long *lists, unsigned long long *pool,
+                                  unsigned *pool_used, unsigned pool_limit)
+{
+    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell < cells)
+        lists[cell] = pack_cell(masks + cell * words, words, pool, pool_used, pool_limit);
+}
+
+// Direction tables of path-ray families (trt_raygrid.h): blockIdx.y = family, one thread per cell.  Every block first forms
+// the cones of its family's apex (the same + - * / sqrt as the host reference builder: the same bits), then each thread
+// marks its cell with the cone / cell predicate of trt_lightgrid.h and packs the list.  `by_value`: the two families of the
+// eye come as kernel arguments (they change with the camera), otherwise family blockIdx.y of `families`.
+__global__ __launch_bounds__(256) void build_family_lists_kernel(const double *spheres, int n, const trt_rayfamily *families, trt_rayfamily f0,
+                                                                 trt_rayfamily f1, int by_value, int g, unsigned long long *lists,
+                                                                 unsigned long long *pool, unsigned *pool_used, unsigned pool_limit)
+{
+    __shared__ trt_pointgrid_cone cones[TRT_LIST_MAX_SPHERES];
+    const trt_rayfamily F = by_value ? (blockIdx.y == 0 ? f0 : f1) : families[blockIdx.y];
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        trt_rayfamily_cone(&F, spheres + 9 * i, &cones[i]);
+    __syncthreads();
+    const unsigned cells = 6u * (unsigned)g * (unsigned)g;
+    const unsigned cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= cells)
+        return;
+    const int face = (int)(cell / ((unsigned)g * (unsigned)g)), j = (int)((cell / (unsigned)g) % (unsigned)g), c = (int)(cell % (unsigned)g);
+    unsigned long long m[TRT_LIST_MAX_SPHERES / 64] = {0, 0, 0, 0};
+    for (int i = 0; i < n; i++)
+        if (trt_pointgrid_reaches(&cones[i], face, c, j, g))
+            m[i >> 6] |= 0x8000000000000000ull >> (i & 63);
+    lists[(size_t)blockIdx.y * cells + cell] = pack_cell(m, (n + 63) / 64 > 0 ? (n + 63) / 64 : 1, pool, pool_used, pool_limit);
+}
+
 // Light-space candidate masks of every light (trt_lightgrid.h), from the context's host copy of the primitives: the
 // host places each grid and prepares one small record per sphere and light, the device marks the cells.
 int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
@@ -242,10 +309,10 @@ int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
     const int n = (int)(ctx->h_spheres.size() / 9), nd = (int)(ctx->h_dir.size() / 6), np = (int)(ctx->h_point.size() / 7);
     const int gd = ctx->dirgrid_cells, gp = ctx->pointgrid_cells;
     trt::GridView &g = ctx->grids;
-    g = trt::GridView{};
+    g.enabled = 0;
     ctx->grids_built_for[0] = gd;
     ctx->grids_built_for[1] = gp;
-    if (gd < 8 || gp < 2 || nd + np == 0)
+    if (gd < 8 || gp < 2 || nd + np == 0 || n > TRT_LIST_MAX_SPHERES)
         return TRT_OK; // enabled = 0: the kernel sweeps
     const size_t words = (size_t)std::max((n + 63) / 64, 1), slots = (size_t)std::max(n, 1);
     const size_t dir_stride = (size_t)gd * gd * words, point_stride = 6 * (size_t)gp * gp * words;
@@ -287,15 +354,115 @@ int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
     for (int i = 0; i < np; i++)
         hipLaunchKernelGGL(build_pointgrid_kernel, dim3((unsigned)((6 * (size_t)gp * gp + block - 1) / block)), dim3(block), 0, ctx->stream,
                            ctx->d_cones.ptr + slots * i, n, gp, (int)words, ctx->d_point_masks.ptr + point_stride * i);
+    // the kernel reads list cells: pack every table (the mask words stay for trt_read_light_grid)
+    const size_t dir_cells = (size_t)gd * gd, point_cells = 6 * (size_t)gp * gp;
+    HIP_TRY(ctx->d_dir_lists.reserve(dir_cells * nd));
+    HIP_TRY(ctx->d_point_lists.reserve(point_cells * np));
+    if (nd)
+        hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((dir_cells * nd + block - 1) / block)), dim3(block), 0, ctx->stream, ctx->d_dir_masks.ptr,
+                           (long)(dir_cells * nd), (int)words, ctx->d_dir_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words);
+    if (np)
+        hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((point_cells * np + block - 1) / block)), dim3(block), 0, ctx->stream, ctx->d_point_masks.ptr,
+                           (long)(point_cells * np), (int)words, ctx->d_point_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // the caller may hand the context another stream before it renders
     g.dir = ctx->d_dirgrids.ptr;
     g.point = ctx->d_pointgrids.ptr;
-    g.dir_masks = ctx->d_dir_masks.ptr;
-    g.point_masks = ctx->d_point_masks.ptr;
-    g.dir_stride = (unsigned)dir_stride;
-    g.point_stride = (unsigned)point_stride;
+    g.dir_lists = ctx->d_dir_lists.ptr;
+    g.point_lists = ctx->d_point_lists.ptr;
+    g.dir_stride = (unsigned)dir_cells;
+    g.point_stride = (unsigned)point_cells;
+    g.pool = ctx->d_pool.ptr;
     g.enabled = 1;
+    return TRT_OK;
+}
+
+// Direction tables of the 2N sphere families of the path rays (trt_raygrid.h); the two families of the eye follow per camera
+// (ensure_eye_tables).  The host places the families (O(N)), the device forms the cones and marks and packs the cells.
+int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const double *ground)
+{
+    const int n = (int)(ctx->h_spheres.size() / 9);
+    trt::GridView &g = ctx->grids;
+    g.path_enabled = 0;
+    ctx->eye_tables_valid = false;
+    ctx->path_built_for[0] = ctx->path_g_eye;
+    ctx->path_built_for[1] = ctx->path_g_sph;
+    ctx->cull_scene = cs;
+    memcpy(ctx->ground_built, ground, sizeof ctx->ground_built);
+    const int ge = ctx->path_g_eye, gs = ctx->path_g_sph;
+    if (ge < 2 || gs < 2 || n > TRT_LIST_MAX_SPHERES)
+        return TRT_OK; // path_enabled = 0: every path ray sweeps
+    const size_t eye_cells = 6 * (size_t)ge * ge, sph_cells = 6 * (size_t)gs * gs;
+    HIP_TRY(ctx->d_path_lists.reserve(2 * eye_cells + 2 * (size_t)n * sph_cells));
+    HIP_TRY(ctx->d_families.reserve(2 * (size_t)std::max(n, 1)));
+    HIP_TRY(ctx->d_sphere_fam.reserve(4 * (size_t)std::max(n, 1)));
+    std::vector<trt_rayfamily> fam(2 * (size_t)std::max(n, 1));
+    std::vector<double> rec(4 * (size_t)std::max(n, 1));
+    trt_sphere_families(ctx->h_spheres.data(), n, ground, &cs, fam.data());
+    for (int i = 0; i < n; i++)
+    {
+        rec[4 * i + 0] = fam[n + i].a[0], rec[4 * i + 1] = fam[n + i].a[1], rec[4 * i + 2] = fam[n + i].a[2];
+        rec[4 * i + 3] = fam[i].r_chk;
+    }
+    if (n)
+    {
+        HIP_TRY(hipMemcpy(ctx->d_families.ptr, fam.data(), 2 * (size_t)n * sizeof(trt_rayfamily), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_sphere_fam.ptr, rec.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((sph_cells + 255) / 256), (unsigned)(2 * n)), dim3(256), 0, ctx->stream,
+                           (const double *)ctx->d_spheres.ptr, n, (const trt_rayfamily *)ctx->d_families.ptr, trt_rayfamily{}, trt_rayfamily{}, 0, gs,
+                           ctx->d_path_lists.ptr + 2 * eye_cells, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    g.path_lists = ctx->d_path_lists.ptr;
+    g.pool = ctx->d_pool.ptr;
+    g.sphere_fam = ctx->d_sphere_fam.ptr;
+    g.rg2_sph = n ? fam[0].rg2 : 0.0;
+    g.g_eye = ge;
+    g.g_sph = gs;
+    g.path_enabled = 1;
+    return TRT_OK;
+}
+
+// Every candidate table of the scene: the pool of long lists is laid out first (one part for the scene's tables, one for
+// the eye's, which are rebuilt per camera), then the light tables, then the sphere families.
+int build_tables(trt_context *ctx, const trt_cull_scene &cs, const double *ground)
+{
+    const size_t n = ctx->h_spheres.size() / 9, nd = ctx->h_dir.size() / 6, np = ctx->h_point.size() / 7;
+    const size_t gd = (size_t)ctx->dirgrid_cells, gp = (size_t)ctx->pointgrid_cells, ge = (size_t)ctx->path_g_eye, gs = (size_t)ctx->path_g_sph;
+    ctx->pool_scene_words = std::max<size_t>(1024, nd * gd * gd + np * 6 * gp * gp + 2 * n * 6 * gs * gs);
+    ctx->pool_eye_words = std::max<size_t>(1024, 2 * 6 * ge * ge);
+    if (ctx->pool_scene_words + ctx->pool_eye_words >= 0xffffffffull)
+        return fail(TRT_ERR_CAPACITY, "candidate tables too large");
+    ctx->grids = trt::GridView{};
+    HIP_TRY(ctx->d_pool.reserve(ctx->pool_scene_words + ctx->pool_eye_words));
+    HIP_TRY(ctx->d_pool_used.reserve(32));
+    HIP_TRY(hipMemsetAsync(ctx->d_pool_used.ptr, 0, 32 * sizeof(unsigned), ctx->stream));
+    int rc = build_light_grids(ctx, cs);
+    if (rc)
+        return rc;
+    return build_path_tables(ctx, cs, ground);
+}
+
+// The two families of the eye (trt_raygrid.h): rebuilt on `stream` whenever the eye (or the scene) changed since they were built.
+int ensure_eye_tables(trt_context *ctx, const Camera *camera, hipStream_t stream)
+{
+    trt::GridView &g = ctx->grids;
+    if (!g.path_enabled)
+        return TRT_OK;
+    const double eye[3] = {camera->frame.origin.x, camera->frame.origin.y, camera->frame.origin.z};
+    if (ctx->eye_tables_valid && !memcmp(eye, ctx->eye_built, sizeof eye))
+        return TRT_OK;
+    trt_eye_families(eye, ctx->ground_built, &ctx->cull_scene, g.eye);
+    const int n = (int)(ctx->h_spheres.size() / 9), ge = g.g_eye;
+    const size_t eye_cells = 6 * (size_t)ge * ge;
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->d_pool_used.ptr + 16), (int)ctx->pool_scene_words, 1, stream));
+    hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((eye_cells + 255) / 256), 2u), dim3(256), 0, stream, (const double *)ctx->d_spheres.ptr, n,
+                       (const trt_rayfamily *)nullptr, g.eye[0], g.eye[1], 1, ge, ctx->d_path_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr + 16,
+                       (unsigned)(ctx->pool_scene_words + ctx->pool_eye_words));
+    HIP_TRY(hipGetLastError());
+    memcpy(ctx->eye_built, eye, sizeof eye);
+    ctx->eye_tables_valid = true;
     return TRT_OK;
 }
 
@@ -339,13 +506,15 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
                       (!n || !memcmp(ctx->h_spheres.data(), hs, (size_t)n * sizeof(Sphere))) &&
                       (!nd || !memcmp(ctx->h_dir.data(), hd, (size_t)nd * sizeof(DirectionalLight))) &&
                       (!np || !memcmp(ctx->h_point.data(), hp, (size_t)np * sizeof(PointLight))) &&
-                      ctx->grids_built_for[0] == ctx->dirgrid_cells && ctx->grids_built_for[1] == ctx->pointgrid_cells;
+                      ctx->grids_built_for[0] == ctx->dirgrid_cells && ctx->grids_built_for[1] == ctx->pointgrid_cells &&
+                      ctx->path_built_for[0] == ctx->path_g_eye && ctx->path_built_for[1] == ctx->path_g_sph &&
+                      !memcmp(ctx->ground_built, &scene->ground, sizeof ctx->ground_built);
     if (!same)
     {
         ctx->h_spheres.assign(hs, hs + (size_t)n * 9);
         ctx->h_dir.assign(hd, hd + (size_t)nd * 6);
         ctx->h_point.assign(hp, hp + (size_t)np * 7);
-        const int rc = build_light_grids(ctx, cs);
+        const int rc = build_tables(ctx, cs, (const double *)&scene->ground);
         if (rc)
         {
             ctx->grids_built_for[0] = ctx->grids_built_for[1] = -1;
@@ -484,6 +653,12 @@ static int init_context(trt_context *ctx)
         if (sscanf(e, "%d,%d", &gd, &gp) == 2 && gd >= 0 && gp >= 0 && gd <= 2048 && gp <= 1024)
             ctx->dirgrid_cells = gd, ctx->pointgrid_cells = gp;
     }
+    if (const char *e = getenv("TRT_PATHGRID"))
+    {
+        int ge = 0, gs = 0;
+        if (sscanf(e, "%d,%d", &ge, &gs) == 2 && ge >= 0 && gs >= 0 && ge <= 1024 && gs <= 256)
+            ctx->path_g_eye = ge, ctx->path_g_sph = gs;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < kEventRing; i++)
@@ -506,6 +681,7 @@ static int init_context(trt_context *ctx)
     (void)hipFuncSetAttribute((const void *)trt::probe_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::probe_rounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     return TRT_OK;
 }
 
@@ -547,6 +723,13 @@ extern "C" int trt_destroy(trt_context *ctx)
     ctx->d_samples_alt.release();
     ctx->d_fb.release();
     ctx->d_cull.release();
+    ctx->d_dir_lists.release();
+    ctx->d_point_lists.release();
+    ctx->d_path_lists.release();
+    ctx->d_pool.release();
+    ctx->d_pool_used.release();
+    ctx->d_families.release();
+    ctx->d_sphere_fam.release();
     ctx->d_dir_masks.release();
     ctx->d_point_masks.release();
     ctx->d_dirgrids.release();
@@ -638,6 +821,14 @@ extern "C" int trt_read_diagnostics(trt_context *ctx, unsigned long long *wave_l
     return TRT_OK;
 }
 
+extern "C" int trt_read_sweep_fallbacks(trt_context *ctx, unsigned long long *swept_traces)
+{
+    if (!ctx || !swept_traces)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    *swept_traces = ctx->last_swept;
+    return TRT_OK;
+}
+
 extern "C" int trt_set_kernel(trt_context *ctx, int which)
 {
     if (!ctx || which < 0 || which > 1)
@@ -660,7 +851,53 @@ extern "C" int trt_set_light_grids(trt_context *ctx, int directional_cells, int 
     std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
     trt_cull_scene cs;
     trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
-    return build_light_grids(ctx, cs);
+    return build_tables(ctx, cs, ctx->scene.ground);
+}
+
+extern "C" int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_cells)
+{
+    if (!ctx || eye_cells < 0 || sphere_cells < 0 || eye_cells > 1024 || sphere_cells > 256)
+        return fail(TRT_ERR_ARGUMENT, "path grids %d, %d", eye_cells, sphere_cells);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still read the old tables
+    ctx->path_g_eye = eye_cells;
+    ctx->path_g_sph = sphere_cells;
+    if (!ctx->have_scene)
+        return TRT_OK;
+    const int n = (int)(ctx->h_spheres.size() / 9);
+    std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
+    trt_cull_scene cs;
+    trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
+    return build_tables(ctx, cs, ctx->scene.ground);
+}
+
+extern "C" long trt_read_path_tables(trt_context *ctx, const Camera *camera, unsigned long long *cells, size_t capacity_cells,
+                                     unsigned long long *pool, size_t capacity_pool, long info[8])
+{
+    if (!ctx || !camera || !cells || !pool || !info)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (!ctx->have_scene)
+        return fail(TRT_ERR_NO_SCENE, "no scene");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int rc = ensure_eye_tables(ctx, camera, ctx->stream);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const trt::GridView &g = ctx->grids;
+    const int n = (int)(ctx->h_spheres.size() / 9);
+    unsigned used[32] = {0};
+    HIP_TRY(hipMemcpy(used, ctx->d_pool_used.ptr, sizeof used, hipMemcpyDeviceToHost));
+    const size_t total = g.path_enabled ? 2 * 6 * (size_t)g.g_eye * g.g_eye + 2 * (size_t)n * 6 * (size_t)g.g_sph * g.g_sph : 0;
+    const size_t pool_words = ctx->pool_scene_words + ctx->pool_eye_words;
+    info[0] = g.path_enabled, info[1] = g.g_eye, info[2] = g.g_sph, info[3] = n, info[4] = (long)total;
+    info[5] = (long)used[0], info[6] = (long)used[16] - (long)ctx->pool_scene_words, info[7] = (long)pool_words;
+    if (!g.path_enabled)
+        return 0;
+    if (capacity_cells < total || capacity_pool < pool_words)
+        return fail(TRT_ERR_CAPACITY, "tables have %zu cells and %zu pool words", total, pool_words);
+    HIP_TRY(hipMemcpy(cells, ctx->d_path_lists.ptr, total * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pool, ctx->d_pool.ptr, pool_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return (long)total;
 }
 
 extern "C" long trt_read_light_grid(trt_context *ctx, int point_light, int index, unsigned long long *masks, size_t capacity_words)
@@ -674,12 +911,13 @@ extern "C" long trt_read_light_grid(trt_context *ctx, int point_light, int index
         return 0;
     if (index >= (point_light ? ctx->scene.num_point : ctx->scene.num_dir))
         return fail(TRT_ERR_ARGUMENT, "light %d", index);
-    const size_t stride = point_light ? g.point_stride : g.dir_stride;
+    const size_t words = (size_t)std::max((ctx->scene.num_spheres + 63) / 64, 1);
+    const size_t stride = (point_light ? g.point_stride : g.dir_stride) * words; // mask words of one light's table
     if (capacity_words < stride)
         return fail(TRT_ERR_CAPACITY, "table has %zu words, buffer %zu", stride, capacity_words);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(masks, (point_light ? g.point_masks : g.dir_masks) + stride * (size_t)index, stride * sizeof(unsigned long long),
+    HIP_TRY(hipMemcpy(masks, (point_light ? ctx->d_point_masks.ptr : ctx->d_dir_masks.ptr) + stride * (size_t)index, stride * sizeof(unsigned long long),
                       hipMemcpyDeviceToHost));
     return (long)stride;
 }
@@ -702,6 +940,7 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
     HIP_TRY(hipMemcpy(c, ctx->d_counters.ptr, sizeof c, hipMemcpyDeviceToHost));
     ctx->last_trips = c[2];
     ctx->last_phase2 = c[3];
+    ctx->last_swept = c[28];
     if (getenv("TRT_PRINT_STAMPS"))
     { // diagnostic builds only (-DTRT_STAMP=1): per-stage wave-cycle sums
         static const char *const names[24] = {"units+primary", "unit(next_dir)", "P set-up", "P sweep", "P exact tests", "P plane",
@@ -781,6 +1020,9 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
     f.bounce_limit = bounce_limit;
     f.spp = rays_per_pixel;
 
+    rc = ensure_eye_tables(ctx, camera, stream); // no-op unless the eye moved (trt_render_host builds them before it forks its streams)
+    if (rc)
+        return rc;
     const long pixels = (long)local_rows * rows->width;
     const size_t lds = scene_lds_bytes(ctx->scene);
     if (ctx->counters_enabled)
@@ -905,6 +1147,12 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
         HIP_TRY(hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking));
     }
     const hipStream_t copy_stream = bands > 1 ? ctx->copy_stream : ctx->stream;
+    if (ctx->have_scene && camera)
+    { // both render streams read the eye's tables: build them before the fork
+        const int rc = ensure_eye_tables(ctx, camera, ctx->stream);
+        if (rc)
+            return rc;
+    }
     if (bands > 1)
     { // the alternate stream starts behind whatever the caller queued on the context's stream before this call
         HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -1103,6 +1351,45 @@ extern "C" int trt_probe_rays(trt_context *ctx, const Ray *rays, size_t n, int *
     HIP_TRY(hipMemcpy(dr, rays, n * sizeof(Ray), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(trt::probe_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), scene_lds_bytes(ctx->scene), ctx->stream,
                        ctx->scene, dr, (long)n, dobj.ptr, dp, dn, dm, dl);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(obj, dobj.ptr, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(point, dp, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(normal, dn, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(material, dm, 5 * n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lit, dl, 3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    buf.release();
+    dobj.release();
+    return TRT_OK;
+}
+
+extern "C" int trt_probe_rays_production(trt_context *ctx, const Camera *camera, const Ray *rays, const int *families, size_t n, int *obj,
+                                         double *point, double *normal, double *material, double *lit)
+{
+    if (!ctx || !camera || !rays || !obj || !point || !normal || !material || !lit)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (!ctx->have_scene)
+        return fail(TRT_ERR_NO_SCENE, "trt_set_scene has not been called");
+    if (n == 0)
+        return TRT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int rc = ensure_eye_tables(ctx, camera, ctx->stream);
+    if (rc)
+        return rc;
+    DeviceBuffer<double> buf;
+    DeviceBuffer<int> dobj;
+    HIP_TRY(buf.reserve(n * (6 + 3 + 3 + 5 + 3)));
+    HIP_TRY(dobj.reserve(2 * n));
+    double *dr = buf.ptr, *dp = dr + 6 * n, *dn = dp + 3 * n, *dm = dn + 3 * n, *dl = dm + 5 * n;
+    HIP_TRY(hipMemcpy(dr, rays, n * sizeof(Ray), hipMemcpyHostToDevice));
+    if (families)
+        HIP_TRY(hipMemcpy(dobj.ptr + n, families, n * sizeof(int), hipMemcpyHostToDevice));
+    trt::FrameView f{};
+    memcpy(f.cam, camera, sizeof(Camera));
+    f.jitter = ctx->d_jitter.ptr; // spp = 0: nothing is read through it
+    hipLaunchKernelGGL(trt::probe_rounds_kernel, dim3((unsigned)((n + trt::kPersistentBlock - 1) / trt::kPersistentBlock)), dim3(trt::kPersistentBlock),
+                       trt::rounds_lds_bytes(ctx->scene, 0), ctx->stream, ctx->scene, ctx->cull, f, ctx->grids, (const double *)dr,
+                       families ? (const int *)(dobj.ptr + n) : (const int *)nullptr, (long)n, dobj.ptr, dp, dn, dm, dl);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(obj, dobj.ptr, n * sizeof(int), hipMemcpyDeviceToHost));

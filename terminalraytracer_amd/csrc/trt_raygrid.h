@@ -71,19 +71,60 @@ TRT_HD void trt_mirror_point(const double p[3], const double p0[3], const double
     out[2] = p[2] - 2.0 * h * nrm[2];
 }
 
-/* Family with apex `apex` for rays that nominally start within `radius` of it (0: the eye; r_i: sphere i); `slack`
- * absorbs the 1e-6 nudge of TRT.c:871-874 and the rounding of hit points. */
-TRT_HD void trt_rayfamily_init(trt_rayfamily *F, const double apex[3], double radius, double slack, const trt_cull_scene *cs)
+/* Slacks of the membership radius: the 1e-6 nudge of TRT.c:871-874 moves a ray's origin off the surface it starts on (and
+ * off the ideal line through a mirror apex), rounded hit points add a little; mirror families inherit their parent's. */
+#define TRT_FAMILY_SLACK 4e-6
+
+TRT_HD void trt_rayfamily_set(trt_rayfamily *F, const double apex[3], double r_chk, double rg)
+{
+    F->a[0] = apex[0], F->a[1] = apex[1], F->a[2] = apex[2];
+    F->r_chk = r_chk;
+    F->r_chk2 = r_chk * r_chk;
+    F->rg2 = rg * rg;
+}
+
+/* the two families of the eye: 0 = rays from the eye, 1 = their reflections by the ground (apex = the eye's mirror image) */
+static inline void trt_eye_families(const double eye[3], const double *ground /* Plane: point, normal */, const trt_cull_scene *cs,
+                                    trt_rayfamily fam[2])
 {
     const double reach = (double)cs->cn + (double)cs->rm;
-    const double lc[3] = {apex[0] - cs->c0[0], apex[1] - cs->c0[1], apex[2] - cs->c0[2]};
-    const double away = __builtin_sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]);
+    double m[3];
+    trt_mirror_point(eye, ground, ground + 3, m);
+    const double *apex[2] = {eye, m};
+    for (int k = 0; k < 2; k++)
+    {
+        const double lc[3] = {apex[k][0] - cs->c0[0], apex[k][1] - cs->c0[1], apex[k][2] - cs->c0[2]};
+        const double away = __builtin_sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]);
+        const double mag = __builtin_fabs(apex[k][0]) + __builtin_fabs(apex[k][1]) + __builtin_fabs(apex[k][2]) + reach;
+        trt_rayfamily_set(&fam[k], apex[k], (k ? TRT_FAMILY_SLACK : 0.0) + 1e-9 * mag, TRT_LIGHTGRID_RANGE * (reach + away) + 1.0);
+    }
+}
+
+/* The 2n families of the spheres: fam[i] = rays starting on sphere i, fam[n + i] = their reflections by the ground (apex = the
+ * mirror image of the centre, membership radius TRT_FAMILY_SLACK larger).  All share one admissible range.  What the
+ * kernel keeps per sphere is {mirror apex (3), r_chk of fam[i]}: it forms r_chk of fam[n + i] as r_chk + TRT_FAMILY_SLACK. */
+static inline void trt_sphere_families(const double *spheres, int n, const double *ground, const trt_cull_scene *cs, trt_rayfamily *fam)
+{
+    const double reach = (double)cs->cn + (double)cs->rm;
+    const double mag = __builtin_fabs(cs->c0[0]) + __builtin_fabs(cs->c0[1]) + __builtin_fabs(cs->c0[2]) + reach + 1.0;
+    double away = reach;
+    for (int i = 0; i < n; i++)
+    {
+        double m[3];
+        trt_mirror_point(spheres + 9 * i, ground, ground + 3, m);
+        const double lc[3] = {m[0] - cs->c0[0], m[1] - cs->c0[1], m[2] - cs->c0[2]};
+        const double far = __builtin_sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]);
+        away = far > away ? far : away; /* NaN (a ground without a normal) leaves it alone; such tables never pass the membership test */
+    }
     const double rg = TRT_LIGHTGRID_RANGE * (reach + away) + 1.0;
-    const double mag = __builtin_fabs(apex[0]) + __builtin_fabs(apex[1]) + __builtin_fabs(apex[2]) + reach;
-    F->a[0] = apex[0], F->a[1] = apex[1], F->a[2] = apex[2];
-    F->r_chk = __builtin_fabs(radius) * (1.0 + 1e-6) + slack + 1e-9 * mag;
-    F->r_chk2 = F->r_chk * F->r_chk;
-    F->rg2 = rg * rg;
+    for (int i = 0; i < n; i++)
+    {
+        double m[3];
+        trt_mirror_point(spheres + 9 * i, ground, ground + 3, m);
+        const double r_chk = __builtin_fabs(spheres[9 * i + 3]) * (1.0 + 1e-6) + TRT_FAMILY_SLACK + 1e-9 * mag;
+        trt_rayfamily_set(&fam[i], spheres + 9 * i, r_chk, rg);
+        trt_rayfamily_set(&fam[n + i], m, r_chk + TRT_FAMILY_SLACK, rg);
+    }
 }
 
 /* does the ray (o, d), d a unit vector up to 2^-40, belong to the family?  false for NaN */

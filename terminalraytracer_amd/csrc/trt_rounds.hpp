@@ -21,34 +21,49 @@
 // modes; the code of each stage is straight-line with exec masking only for "hit" vs "sky".  The price is
 // that lanes whose path ray reached the sky idle through the shadow stages of that round.
 //
-// The trace itself is a two-phase search.  Phase 1 proposes candidate spheres: for a PATH ray a wave-uniform FP32
-// sweep over a culling table in LDS (trt_filter.h: broadcast ds_read_b128, 9 VALU per sphere, verdict in a sign
-// bit); for a SHADOW ray one look-up in the light's table in light space (trt_lightgrid.h: the rays towards one
-// light are a two-parameter family), with the sweep as the fall-back for origins outside the table's range.
-// Phase 2 is per lane: the EXACT FP64 test of the few candidates in ascending index order.  Neither filter ever
-// decides a hit.  FP64, contraction off: results are bit-identical to the reference.  The mean over a pixel's
-// samples is formed by reduce_samples_kernel in the reference's order (TRT.c:1063-1065).
+// The trace itself is a two-phase search.  Phase 1 proposes candidate spheres with ONE table look-up per ray: path rays
+// come in families that (nearly) pass through one point -- the eye, its mirror image in the ground, a sphere, a sphere's
+// mirror image -- and each family has a cube map of direction cells (trt_raygrid.h); the shadow rays of one light are a
+// two-parameter family too (trt_lightgrid.h).  A cell is one 64-bit word holding up to seven sphere indices (longer lists
+// live in a pool).  A ray that does not pass its family's membership test, or whose origin is outside a light table's
+// range, makes its wave fall back to the wave-uniform FP32 sweep over a culling table in LDS (trt_filter.h: broadcast
+// ds_read_b128, 9 VALU per sphere, verdict in a sign bit).  Phase 2 is per lane: the EXACT FP64 test of the few candidates
+// in ascending index order.  No table or filter ever decides a hit.  FP64, contraction off: results are bit-identical to the
+// reference.  The mean over a pixel's samples is formed by reduce_samples_kernel in the reference's order (TRT.c:1063-1065).
 #pragma once
 
 #include "trt_device.hpp"
 #include "trt_filter.h"
 #include "trt_lightgrid.h"
+#include "trt_raygrid.h"
 #include "trt_common.hpp"
 
 namespace trt
 {
 
 
-// Light-space candidate masks (trt_lightgrid.h): per light one table of cells, each cell `words` 64-bit masks.
+// Candidate tables.  Every table cell is one 64-bit LIST CELL (trt_raygrid.h): up to seven sphere indices inline, longer
+// lists in `pool`.
 struct GridView
 {
+    // light-space tables of the shadow rays (trt_lightgrid.h): headers and one list cell per table cell
     const trt_dirgrid *dir;     // [num_dir]
     const trt_pointgrid *point; // [num_point]
-    const unsigned long long *dir_masks, *point_masks;
-    unsigned dir_stride, point_stride; // words per light
+    const unsigned long long *dir_lists, *point_lists;
+    unsigned dir_stride, point_stride; // cells per light
     int enabled;
+    // direction tables of the path rays' families (trt_raygrid.h): families 0 (eye) and 1 (mirror eye) have 6*g_eye^2 cells
+    // each, then 2N families (sphere i, then mirror sphere i) of 6*g_sph^2 cells
+    int path_enabled;
+    int g_eye, g_sph;
+    const unsigned long long *path_lists;
+    const unsigned long long *pool;
+    const double *sphere_fam; // per sphere: mirror image of the centre (3), r_chk of the sphere's family
+    double rg2_sph;           // admissible |o - apex|^2 of the 2N sphere families
+    trt_rayfamily eye[2];     // families 0 and 1, by value: they change with the camera
 };
 
+static_assert(sizeof(trt_rayfamily) == 8 * TRT_RAYFAMILY_DOUBLES, "families of the eye in the LDS image");
 static_assert(sizeof(trt_dirgrid) == 8 * kDirGridDoubles && sizeof(trt_pointgrid) == 8 * kPointGridDoubles, "light-table headers in the LDS image");
 
 struct LdsImage
@@ -64,18 +79,22 @@ struct LdsImage
     const double *jit;   // jitter x[spp], y[spp]
     const trt_dirgrid *dirgrid;     // headers of the light-space tables (trt_lightgrid.h), per directional light
     const trt_pointgrid *pointgrid; // per point light
+    const double *fam;              // per sphere: mirror image of the centre (3), r_chk of the sphere's family (trt_raygrid.h)
+    const double *eye;              // the two families of the eye: 2 x {apex (3), r_chk, r_chk^2, rg^2}
 };
 
 // LDS image of a workgroup: culling table {Cx,Cy,Cz,kk} (4 floats per sphere, 16-B aligned, first) | cx[n] cy[n] cz[n] r2[n] |
 // mat[(n+2)*5] (spheres, ground even, ground odd) | dir lights: unit to-light(3) colour(3) | point lights: pos(3) colour(3)
 // intensity | byte/255.0 [256] | camera | jitter x[spp] y[spp] | one fixed-direction culling table per directional
-// light | headers of the light-space tables.  rounds_lds_bytes and stage_lds_image must agree.
+// light | headers of the light-space tables | per sphere {mirror centre, r_chk} of the path-ray families.
+// rounds_lds_bytes and stage_lds_image must agree.
 inline size_t rounds_lds_bytes(const SceneView &s, int spp)
 {
     const size_t padded = ((size_t)s.num_spheres + kCullGroup - 1) / kCullGroup * kCullGroup;
     return sizeof(double) * (padded * 2 + (size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * 6 +
                              (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp + 1 /* 16-B alignment */ +
-                             (size_t)s.num_dir * padded * 2 + (size_t)s.num_dir * kDirGridDoubles + (size_t)s.num_point * kPointGridDoubles);
+                             (size_t)s.num_dir * padded * 2 + (size_t)s.num_dir * kDirGridDoubles + (size_t)s.num_point * kPointGridDoubles +
+                             (size_t)s.num_spheres * 4 + 2 * TRT_RAYFAMILY_DOUBLES);
 }
 
 TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView &cull, const FrameView &f, const GridView &grids)
@@ -136,9 +155,17 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
         for (int i = threadIdx.x; i < np * kPointGridDoubles; i += blockDim.x)
             l_pointgrid[i] = ((const double *)grids.point)[i];
     }
+    double *l_fam = l_pointgrid + np * kPointGridDoubles, *l_eye = l_fam + 4 * n;
+    if (grids.path_enabled)
+    {
+        for (int i = threadIdx.x; i < n * 4; i += blockDim.x)
+            l_fam[i] = grids.sphere_fam[i];
+        for (int i = threadIdx.x; i < 2 * TRT_RAYFAMILY_DOUBLES; i += blockDim.x)
+            l_eye[i] = ((const double *)grids.eye)[i];
+    }
     __syncthreads();
     return LdsImage{l_cull, l_cull_dir, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit,
-                    (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid};
+                    (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid, l_fam, l_eye};
 }
 
 struct Hit
@@ -149,15 +176,52 @@ struct Hit
 };
 
 
+// One EXACT sphere test of TRT.c:638-672 in the reference's operation order, folded into the running closest hit of
+// TRT.c:808-826 (strict '<': the first index wins ties).  Predicated rather than branched: a lane without a candidate
+// (`valid` false) tests sphere 0 and discards the result.  Returns true when an ANY_HIT search is answered.
+template <bool ANY_HIT>
+TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool valid, Hit &best)
+{
+    const d3 c = d3{L.cx[i], L.cy[i], L.cz[i]};
+    const d3 oc = sub(o, c);
+    const double b = 2.0 * dot(oc, d);
+    const double cc = dot(oc, oc) - L.r2[i];
+    const double disc = b * b - 4.0 * a * cc;
+    bool done = false;
+    if (valid && !(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
+    { // no further branches: selects keep `best` in place (nested ifs cost five register copies per level)
+        const double t0 = (-b - sqrt_exact(disc)) / (2.0 * a);
+        const bool hit = t0 > 0.0;
+        if (ANY_HIT)
+        { // "anything in the way?" (TRT.c:908): the first hit answers it; its position is never used
+            best.i = hit ? i : best.i;
+            done = hit;
+        }
+        else
+        {
+            const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
+            const double d2 = dist2(o, p);
+            const bool closer = hit && d2 < best.d2;
+            best.d2 = closer ? d2 : best.d2;
+            best.p.x = closer ? p.x : best.p.x;
+            best.p.y = closer ? p.y : best.p.y;
+            best.p.z = closer ? p.z : best.p.z;
+            best.i = closer ? i : best.i;
+        }
+    }
+    return done;
+}
+
 // Closest hit of TRT.c:793-856 for the lanes with `active`.  ANY_HIT: the caller only asks whether anything
 // is hit (directional-light shadow ray, TRT.c:908), so a lane stops at its first hit and the ground is skipped
-// once a sphere was found.  `fixed` != nullptr: all rays share the direction that culling table was built for.
-// `use_masks` (wave-uniform): the candidates come from this lane's cell of a light-space table (`masks`, one word per
-// chunk of 64 spheres) instead of the sweep.
+// once a sphere was found.
+// `use_list` (wave-uniform): every active lane's candidates are the entries of its LIST CELL `cell` (trt_raygrid.h;
+// indices ascending, up to seven inline, longer lists in `pool`).  Otherwise the wave sweeps the FP32 culling table
+// (trt_filter.h) -- `fixed` != nullptr: all rays share the direction that culling table was built for -- and each lane
+// pops its candidate bits.
 template <bool ANY_HIT>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
-                  int lane, const float4 *fixed = nullptr, bool use_masks = false,
-                  const unsigned long long *masks = nullptr
+                  const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool
 #if TRT_STAMP
                   ,
                   unsigned long long *stamp_sum = nullptr, unsigned long long *stamp_prev_p = nullptr, int stamp_base = 0
@@ -173,99 +237,90 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     {                      \
     } while (0)
 #endif
-    (void)lane;
     (void)fixed;
     Hit best;
     best.d2 = __builtin_inf();
     best.p = o;
     best.i = -1;
     const double a = dot(d, d);
-    trt_ray_filter flt;
-    if (!use_masks)
-        trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
-
-    for (int base = 0; base < cull.padded; base += 64)
+    if (use_list)
     {
-        // phase 1: wave-uniform sweep; each verdict is a sign bit shifted into a per-lane word by v_alignbit,
-        // sphere base+j ends up at bit 63-j of `cand`
-        const int chunk = (cull.padded - base) < 64 ? (cull.padded - base) : 64;
-        unsigned long long cand;
-        if (use_masks)
-        {
-            cand = active ? masks[base >> 6] : 0ull;
+        const unsigned ctl = (unsigned)(cell >> 56);
+        const bool pooled = (ctl & TRT_LIST_POOLED) != 0;
+        int count = active ? (pooled ? (int)((cell >> 32) & 0xffffu) : (int)ctl) : 0;
+        const unsigned at = (unsigned)cell; // pooled: offset of the list's words
+        unsigned long long cur = cell;
+        int k = 0;
 #if TRT_STAMP
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-            TRT_TRACE_STAMP(0); // set-up / table load
-        }
-        else
+        TRT_TRACE_STAMP(0); // table load
+        TRT_TRACE_STAMP(1);
+        while (__any(k < count))
         {
-        TRT_TRACE_STAMP(0);
-        unsigned word[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-        {
-            const int first = base + 32 * h, count = (chunk - 32 * h) < 32 ? (chunk - 32 * h) : 32;
-            unsigned bits = ~0u;
-            for (int g = 0; g < count; g += kCullGroup)
-            {
-#pragma unroll
-                for (int j = 0; j < kCullGroup; j++)
-                {
-                    if (ANY_HIT && fixed)
-                    {
-                        const float4 e = fixed[first + g + j];
-                        bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign_fixed_dir(&flt, e.x, e.y, e.z, e.w), 31);
-                    }
-                    else
-                    {
-                        const float4 e = L.cull[first + g + j]; // same address in every lane: LDS broadcast
-                        bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign(&flt, e.x, e.y, e.z, e.w), 31);
-                    }
-                }
-            }
-            word[h] = count > 0 ? ~(bits << (32 - count)) & (count == 32 ? ~0u : ~((1u << (32 - count)) - 1u)) : 0u;
-        }
-        cand = ((unsigned long long)word[0] << 32) | word[1];
-        if (!flt.ok)
-            cand = chunk == 64 ? ~0ull : ~((1ull << (64 - chunk)) - 1ull); // degenerate ray: every sphere of the chunk
-        if (!active)
-            cand = 0;
-        TRT_TRACE_STAMP(1); // sweep
-        }
-        // phase 2: exact FP64 tests of this lane's candidates, ascending index (first index wins ties, TRT.c:816)
-        while (__any(cand != 0))
-        { // predicated rather than branched: a lane without a candidate tests sphere 0 and discards the result
             phase2_rounds++;
-            const int lead = __builtin_clzll(cand | 1ull);
-            const bool valid = cand != 0 && base + lead < n;
-            const int i = valid ? base + lead : 0;
-            cand &= ~(0x8000000000000000ull >> lead);
-            const d3 c = d3{L.cx[i], L.cy[i], L.cz[i]};
-            const d3 oc = sub(o, c);
-            const double b = 2.0 * dot(oc, d);
-            const double cc = dot(oc, oc) - L.r2[i];
-            const double disc = b * b - 4.0 * a * cc;
-            if (valid && !(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
-            { // no further branches: selects keep `best` in place (nested ifs cost five register copies per level)
-                const double t0 = (-b - sqrt_exact(disc)) / (2.0 * a);
-                const bool hit = t0 > 0.0;
-                if (ANY_HIT)
-                { // "anything in the way?" (TRT.c:908): the first hit answers it; its position is never used
-                    best.i = hit ? i : best.i;
-                    cand = hit ? 0ull : cand;
-                }
-                else
+            const bool valid = k < count;
+            if (__any(valid && pooled && (k & 7) == 0))
+                if (valid && pooled && (k & 7) == 0)
+                    cur = pool[at + ((unsigned)k >> 3)];
+            const int i = valid ? (int)((unsigned)cur & 0xffu) : 0;
+            cur >>= 8;
+            k++;
+            if (exact_step<ANY_HIT>(L, o, d, a, i, valid, best))
+                count = 0;
+        }
+    }
+    else
+    {
+        trt_ray_filter flt;
+        trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
+        TRT_TRACE_STAMP(0);
+        for (int base = 0; base < cull.padded; base += 64)
+        {
+            // phase 1: wave-uniform sweep; each verdict is a sign bit shifted into a per-lane word by v_alignbit,
+            // sphere base+j ends up at bit 63-j of `cand`
+            const int chunk = (cull.padded - base) < 64 ? (cull.padded - base) : 64;
+            unsigned word[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+            {
+                const int first = base + 32 * h, count = (chunk - 32 * h) < 32 ? (chunk - 32 * h) : 32;
+                unsigned bits = ~0u;
+                for (int g = 0; g < count; g += kCullGroup)
                 {
-                    const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
-                    const double d2 = dist2(o, p);
-                    const bool closer = hit && d2 < best.d2;
-                    best.d2 = closer ? d2 : best.d2;
-                    best.p.x = closer ? p.x : best.p.x;
-                    best.p.y = closer ? p.y : best.p.y;
-                    best.p.z = closer ? p.z : best.p.z;
-                    best.i = closer ? i : best.i;
+#pragma unroll
+                    for (int j = 0; j < kCullGroup; j++)
+                    {
+                        if (ANY_HIT && fixed)
+                        {
+                            const float4 e = fixed[first + g + j];
+                            bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign_fixed_dir(&flt, e.x, e.y, e.z, e.w), 31);
+                        }
+                        else
+                        {
+                            const float4 e = L.cull[first + g + j]; // same address in every lane: LDS broadcast
+                            bits = __builtin_amdgcn_alignbit(bits, trt_filter_sign(&flt, e.x, e.y, e.z, e.w), 31);
+                        }
+                    }
                 }
+                word[h] = count > 0 ? ~(bits << (32 - count)) & (count == 32 ? ~0u : ~((1u << (32 - count)) - 1u)) : 0u;
+            }
+            unsigned long long cand = ((unsigned long long)word[0] << 32) | word[1];
+            if (!flt.ok)
+                cand = chunk == 64 ? ~0ull : ~((1ull << (64 - chunk)) - 1ull); // degenerate ray: every sphere of the chunk
+            if (!active)
+                cand = 0;
+            TRT_TRACE_STAMP(1); // sweep
+            // phase 2: exact FP64 tests of this lane's candidates, ascending index (first index wins ties, TRT.c:816)
+            while (__any(cand != 0))
+            {
+                phase2_rounds++;
+                const int lead = __builtin_clzll(cand | 1ull);
+                const bool valid = cand != 0 && base + lead < n;
+                const int i = valid ? base + lead : 0;
+                cand &= ~(0x8000000000000000ull >> lead);
+                if (exact_step<ANY_HIT>(L, o, d, a, i, valid, best))
+                    cand = 0ull;
             }
         }
     }
@@ -295,6 +350,219 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     return best;
 }
 
+// The list cell of a PATH ray (trt_raygrid.h).  `fam`: the family the ray is expected in (0 eye, 1 mirror eye, 2 + i sphere
+// i, 2 + n + i mirror sphere i, < 0 none).  `fallback` is set for an active lane whose ray fails the family's membership
+// test (its line must pass within r_chk of the apex, its origin not more than r_chk behind it, within the table's range; a
+// unit direction) or whose cell has no list: the caller then sweeps.
+TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n, int fam, d3 o, d3 d, bool active, bool &fallback)
+{
+    const bool has = active && fam >= 0;
+    const int f = has ? fam : 0;
+    const int s = f >= 2 ? f - 2 : 0, i = s >= n ? s - n : s; // sphere of the family
+    const bool of_eye = f < 2, mirrored = s >= n;
+    const double *rec = L.fam + 4 * i;
+    d3 apex = mirrored ? load3(rec) : d3{L.cx[i], L.cy[i], L.cz[i]};
+    double r_chk = mirrored ? rec[3] + TRT_FAMILY_SLACK : rec[3];
+    double rg2 = G.rg2_sph;
+    if (of_eye)
+    {
+        const double *E = L.eye + TRT_RAYFAMILY_DOUBLES * (f & 1);
+        apex = load3(E);
+        r_chk = E[3];
+        rg2 = E[5];
+    }
+    // trt_rayfamily_member, operation for operation
+    const d3 w = sub(o, apex);
+    const d3 c = d3{w.y * d.z - w.z * d.y, w.z * d.x - w.x * d.z, w.x * d.y - w.y * d.x};
+    const bool member = dot(c, c) <= r_chk * r_chk && dot(w, d) >= -r_chk && dot(w, w) <= rg2 &&
+                        __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
+    const int g = of_eye ? G.g_eye : G.g_sph;
+    const int at = trt_cubemap_cell((float)d.x, (float)d.y, (float)d.z, 0.5f * (float)g, (float)(g - 1), g);
+    const unsigned eye_cells = 6u * (unsigned)G.g_eye * (unsigned)G.g_eye, sph_cells = 6u * (unsigned)G.g_sph * (unsigned)G.g_sph;
+    const unsigned base = of_eye ? (unsigned)f * eye_cells : 2u * eye_cells + (unsigned)s * sph_cells;
+    unsigned long long cell = 0;
+    if (has && member)
+        cell = G.path_lists[base + (unsigned)at];
+    fallback = active && (!has || !member || (unsigned)(cell >> 56) == TRT_LIST_NONE);
+    return cell;
+}
+
+// Per-lane counters of the counting kernel variant and the stamps of the diagnostic build, handed through the stages.
+struct Tally
+{
+    unsigned path = 0, shadow = 0, rounds = 0, phase2 = 0, swept = 0;
+#if TRT_STAMP
+    unsigned long long stamp_sum[24] = {0}, stamp_prev = 0;
+#endif
+};
+#if TRT_STAMP
+#define TRT_STAGE_STAMPS(t)                       \
+    unsigned long long *const stamp_sum = (t).stamp_sum; \
+    unsigned long long &stamp_prev = (t).stamp_prev
+#else
+#define TRT_STAGE_STAMPS(t) (void)(t)
+#endif
+
+// What the path ray of a round found (TRT.c:793-889).
+struct PathHit
+{
+    Hit ph;     // closest hit as the intersection routine produced it (un-nudged point)
+    bool hit;   // a sphere or the ground
+    bool sky;   // nothing: the sample ends on the sky
+    d3 back;    // hit: unit vector back along the ray (nudge direction, TRT.c:871-872); sky: the unit direction (TRT.c:702, :878)
+    d3 normal;  // hit: unit surface normal (TRT.c:878)
+    int mat;    // hit: index into L.mat (sphere i, n = ground even, n + 1 = ground odd; TRT.c:850-851)
+};
+
+// P: closest hit of the path ray (o, d) of every lane with `alive`, candidates from the table of the ray's family `fam`
+// (trt_raygrid.h) unless some lane's ray is not a member of its family; then the surface record.  `fam` becomes the family of
+// the NEXT path ray: it starts on the sphere that was hit, or it is the mirror image in the ground of a ray of this one's
+// family (a ray from the ground cannot hit the ground again; if it does, it has no family).
+template <bool COUNT>
+TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridView &grids, int n, d3 o, d3 d, int &fam, bool alive, d3 gp, d3 gn,
+                           Tally &tally)
+{
+    TRT_STAGE_STAMPS(tally);
+    bool p_list = false;
+    unsigned long long p_cell = 0;
+    if (grids.path_enabled)
+    {
+        bool fallback;
+        p_cell = path_cell(L, grids, n, fam, o, d, alive, fallback);
+        p_list = !__any(fallback);
+    }
+    if (COUNT && !p_list)
+        tally.swept++;
+    PathHit r;
+#if TRT_STAMP
+    r.ph = trace<false>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, stamp_sum, &stamp_prev, 2);
+#else
+    r.ph = trace<false>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool);
+#endif
+    r.hit = alive && r.ph.i >= 0;
+    r.sky = alive && r.ph.i < 0;
+    if (r.hit)
+        fam = r.ph.i < n ? 2 + r.ph.i : (fam == 0 ? 1 : (fam >= 2 && fam < 2 + n ? fam + n : -1));
+    // one unit() for "back along the ray" (nudge, TRT.c:871-872) or the sky direction (TRT.c:702), one for the normal
+    r.back = unit(r.hit ? sub(o, r.ph.p) : d);
+    r.normal = d;
+    r.mat = 0;
+    if (__any(r.hit))
+    {
+        d3 raw = gn;
+        r.mat = n + checker_odd(r.ph.p); // TRT.c:850-851 (only meaningful for a ground hit)
+        if (r.ph.i >= 0 && r.ph.i < n)
+        {
+            raw = sub(r.ph.p, d3{L.cx[r.ph.i], L.cy[r.ph.i], L.cz[r.ph.i]}); // TRT.c:824
+            r.mat = r.ph.i;
+        }
+        r.normal = unit(raw); // TRT.c:878
+    }
+    TRT_STAMP_AT(6); // P post: nudge direction, normal
+    return r;
+}
+
+// S(i): lighting of TRT.c:894-957 for the lanes with `lit_lanes`: one shadow ray per light from the (nudged) surface point
+// `o` with unit normal `normal`, candidates from the light's table (trt_lightgrid.h) unless some lane's origin is outside
+// its range; the lit colour is accumulated in the reference's light order, NOT yet clamped (TRT.c:960).
+template <bool COUNT>
+TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView &grids, int n, int nd, int nl, d3 o, d3 normal, int mat,
+                        bool lit_lanes, d3 gp, d3 gn, Tally &tally)
+{
+    TRT_STAGE_STAMPS(tally);
+    d3 lit = d3{0.0, 0.0, 0.0};
+    if (!__any(lit_lanes))
+        return lit;
+    for (int li = 0; li < nl; li++)
+    {
+        if (COUNT && lit_lanes)
+            tally.shadow++;
+        d3 sd, lcolor;
+        bool is_lit;
+        double factor;
+        if (li < nd)
+        { // directional light, TRT.c:900-923
+            sd = load3(L.dir + li * 6);
+            lcolor = load3(L.dir + li * 6 + 3);
+            bool use_list = false;
+            unsigned long long cell = 0;
+            if (grids.enabled)
+            {
+                const trt_dirgrid *G = L.dirgrid + li; // header in LDS: a global read here would sit in front of the cell's load
+                int far;
+                const int c = trt_dirgrid_cell(G, o.x, o.y, o.z, &far);
+                far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
+                if (lit_lanes && !far)
+                    cell = grids.dir_lists[(size_t)li * grids.dir_stride + (unsigned)c];
+                use_list = !__any(lit_lanes && (far || (unsigned)(cell >> 56) == TRT_LIST_NONE));
+            }
+            if (COUNT && !use_list)
+                tally.swept++;
+            TRT_STAMP_AT(8); // look-up
+#if TRT_STAMP
+            const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, L.cull_dir + li * cull.padded, use_list, cell, grids.pool,
+                                       stamp_sum, &stamp_prev, 9);
+#else
+            const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, L.cull_dir + li * cull.padded, use_list, cell, grids.pool);
+#endif
+            is_lit = sh.i < 0;
+            factor = min1(dot(normal, sd));
+            TRT_STAMP_AT(13); // directional shadow tail
+        }
+        else
+        { // point light, TRT.c:926-957
+            const double *pl = L.pt + (li - nd) * 7;
+            const d3 to_light = sub(load3(pl), o);
+            const double light_d2 = dot(to_light, to_light);
+            const double strength = clampd(pl[6] / light_d2, 0.0, 1.0);
+            sd = unit(to_light);
+            lcolor = load3(pl + 3);
+            bool use_list = false;
+            unsigned long long cell = 0;
+            if (grids.enabled)
+            {
+                const trt_pointgrid *G = L.pointgrid + (li - nd);
+                int far;
+                const int c = trt_pointgrid_cell(G, o.x, o.y, o.z, &far);
+                far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
+                if (lit_lanes && !far)
+                    cell = grids.point_lists[(size_t)(li - nd) * grids.point_stride + (unsigned)c];
+                use_list = !__any(lit_lanes && (far || (unsigned)(cell >> 56) == TRT_LIST_NONE));
+            }
+            if (COUNT && !use_list)
+                tally.swept++;
+            TRT_STAMP_AT(14); // unit(to_light), strength, look-up
+#if TRT_STAMP
+            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool, stamp_sum, &stamp_prev, 15);
+#else
+            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool);
+#endif
+            is_lit = sh.i < 0;
+            // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the
+            // blocker point NUDGED 1e-6 back along the ray (TRT.c:871-874, :939-942): (D - 1e-6)^2 up to ~1e-14 relative
+            // rounding, where D^2 = sh.d2 (1 +- 4u).  From D <= (D^2+1)/2:
+            //     (D-1e-6)^2 (1-1e-14)  >=  sh.d2 (1 - 1.01e-6) - 1.01e-6      and, for D >= 1e-5,   (D-1e-6)^2 (1+1e-14) < sh.d2.
+            // Outside that band the answer is certain without normalising anything; inside it (about one ray in 1e5)
+            // the exact nudged point is formed as the reference does.
+            const bool surely_lit = light_d2 < sh.d2 * (1.0 - 1.01e-6) - 1.01e-6;
+            const bool surely_dark = sh.d2 > 1e-10 && light_d2 >= sh.d2;
+            if (sh.i >= 0)
+                is_lit = surely_lit;
+            if (__any(lit_lanes && sh.i >= 0 && !surely_lit && !surely_dark))
+            {
+                const d3 to_blocker = sub(add(sh.p, scale(unit(sub(o, sh.p)), 0.000001)), o);
+                if (sh.i >= 0 && !surely_lit && !surely_dark)
+                    is_lit = light_d2 < dot(to_blocker, to_blocker);
+            }
+            factor = strength * min1(dot(normal, sd));
+            TRT_STAMP_AT(19); // point shadow tail
+        }
+        if (lit_lanes && is_lit)
+            lit = add(lit, mulc(scale(lcolor, factor), load3(L.mat + mat * 5)));
+    }
+    return lit;
+}
+
 // Register budget: asking the allocator for only 3 waves/SIMD lets it settle at 127 VGPRs -- which still runs 4 waves/SIMD
 // (<= 128) -- with a better schedule than when it is forced under 128 (measured 3.02 vs 3.15 ms).  The build records the
 // compiler's resource report in build/resource_usage.txt and `make lib` warns if this kernel ever needs more than 128.
@@ -322,11 +590,12 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
     int bounces = 0;
     d3 o = d3{0.0, 0.0, 0.0}, d = d3{0.0, 0.0, -1.0}; // the pending path ray
     d3 next_dir = d;                                  // un-normalised direction of the next path ray
-    unsigned n_path = 0, n_shadow = 0, n_rounds = 0, n_phase2 = 0;
+    int fam = 0;                                      // family of the pending path ray (trt_raygrid.h): 0 = it starts at the eye
+    Tally tally;
     unsigned pool_next = 0, pool_end = 0; // wave-uniform: units fetched from the queue, not yet handed out
 
+    TRT_STAGE_STAMPS(tally);
 #if TRT_STAMP
-    unsigned long long stamp_sum[24] = {0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     for (;;)
@@ -382,6 +651,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                         dir = add(dir, scale(load3(L.cam + 6), L.cam[12]));
                         next_dir = sub(dir, load3(L.cam + 9)); // sic, TRT.c:1005
                         o = load3(L.cam + 9);
+                        fam = 0;
                         sample = d3{0.0, 0.0, 0.0};
                         weight = 1.0;
                         weight_sum = 0.0;
@@ -394,140 +664,36 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
         if (!__any(alive))
             break;
         if (COUNT)
-            n_rounds++;
+            tally.rounds++;
         TRT_STAMP_AT(0); // units + primary rays
         d = unit(next_dir); // TRT.c:1008 for a primary ray, TRT.c:1055 for a reflected one
 
         // ======================================= P: the path ray =======================================
         if (COUNT && alive)
-            n_path++;
+            tally.path++;
         TRT_STAMP_AT(1); // unit(next_dir)
-#if TRT_STAMP
-        const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2, lane, nullptr, false, nullptr, stamp_sum, &stamp_prev, 2);
-#else
-        const Hit ph = trace<false>(L, cull, n, o, d, alive, gp, gn, n_phase2, lane);
-#endif
-        const bool path_hit = alive && ph.i >= 0, path_sky = alive && ph.i < 0;
-
-        // one unit() for "back along the ray" (nudge, TRT.c:871-872) or the sky direction (TRT.c:702), one for the normal
-        const d3 nA = unit(path_hit ? sub(o, ph.p) : d);
-        d3 h_normal = d, lit = d3{0.0, 0.0, 0.0};
-        int h_mat = 0;
-        if (__any(path_hit))
-        {
-            d3 raw = gn;
-            h_mat = n + checker_odd(ph.p); // TRT.c:850-851 (only meaningful for a ground hit)
-            if (ph.i >= 0 && ph.i < n)
-            {
-                raw = sub(ph.p, d3{L.cx[ph.i], L.cy[ph.i], L.cz[ph.i]}); // TRT.c:824
-                h_mat = ph.i;
-            }
-            h_normal = unit(raw); // TRT.c:878
-        }
-        TRT_STAMP_AT(6); // P post: nudge direction, normal
+        const PathHit hit = path_stage<COUNT>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally);
+        const bool path_hit = hit.hit, path_sky = hit.sky;
+        const d3 h_normal = hit.normal;
+        const int h_mat = hit.mat;
         bool end_sample = false;
         double weight_sum_new = weight_sum + weight; // TRT.c:1034
         if (path_sky)
         { // TRT.c:858-867, :1044-1048: colour = texel, the sample ends here
-            const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, nA);
+            const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, hit.back);
             const d3 color = d3{L.b255[t & 0xFF], L.b255[(t >> 8) & 0xFF], L.b255[(t >> 16) & 0xFF]};
             sample = add(sample, scale(color, weight));
             end_sample = true;
         }
         if (path_hit)
         {
-            next_dir = reflect(d, h_normal);        // TRT.c:1054, normalised at the top of the next round
-            o = add(ph.p, scale(nA, 0.000001));     // TRT.c:873-874; origin of the shadow rays and of the next path ray
+            next_dir = reflect(d, h_normal);              // TRT.c:1054, normalised at the top of the next round
+            o = add(hit.ph.p, scale(hit.back, 0.000001)); // TRT.c:873-874; origin of the shadow rays and of the next path ray
         }
 
         TRT_STAMP_AT(7); // P post: sky texel, reflection, nudge
         // ======================================= S(i): shadow rays =======================================
-        if (__any(path_hit))
-        {
-            for (int li = 0; li < nl; li++)
-            {
-                if (COUNT && path_hit)
-                    n_shadow++;
-                d3 sd, lcolor;
-                bool is_lit;
-                double factor;
-                if (li < nd)
-                { // directional light, TRT.c:900-923
-                    sd = load3(L.dir + li * 6);
-                    lcolor = load3(L.dir + li * 6 + 3);
-                    // candidates from the light's table unless some lane's origin is outside its range (trt_lightgrid.h)
-                    bool use_masks = false;
-                    const unsigned long long *cell = nullptr;
-                    if (grids.enabled)
-                    {
-                        const trt_dirgrid *G = L.dirgrid + li; // header in LDS: a global read here would sit in front of the cell's load
-                        int far;
-                        const int c = trt_dirgrid_cell(G, o.x, o.y, o.z, &far);
-                        far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
-                        use_masks = !__any(path_hit && far);
-                        cell = grids.dir_masks + (size_t)li * grids.dir_stride + (unsigned)c * (unsigned)G->words;
-                    }
-                    TRT_STAMP_AT(8); // look-up
-#if TRT_STAMP
-                    const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, L.cull_dir + li * cull.padded,
-                                               use_masks, cell, stamp_sum, &stamp_prev, 9);
-#else
-                    const Hit sh = trace<true>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, L.cull_dir + li * cull.padded,
-                                               use_masks, cell);
-#endif
-                    is_lit = sh.i < 0;
-                    factor = min1(dot(h_normal, sd));
-                    TRT_STAMP_AT(13); // directional shadow tail
-                }
-                else
-                { // point light, TRT.c:926-957
-                    const double *pl = L.pt + (li - nd) * 7;
-                    const d3 to_light = sub(load3(pl), o);
-                    const double light_d2 = dot(to_light, to_light);
-                    const double strength = clampd(pl[6] / light_d2, 0.0, 1.0);
-                    sd = unit(to_light);
-                    lcolor = load3(pl + 3);
-                    bool use_masks = false;
-                    const unsigned long long *cell = nullptr;
-                    if (grids.enabled)
-                    {
-                        const trt_pointgrid *G = L.pointgrid + (li - nd);
-                        int far;
-                        const int c = trt_pointgrid_cell(G, o.x, o.y, o.z, &far);
-                        far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
-                        use_masks = !__any(path_hit && far);
-                        cell = grids.point_masks + (size_t)(li - nd) * grids.point_stride + (unsigned)c * (unsigned)G->words;
-                    }
-                    TRT_STAMP_AT(14); // unit(to_light), strength, look-up
-#if TRT_STAMP
-                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, nullptr, use_masks, cell, stamp_sum, &stamp_prev, 15);
-#else
-                    const Hit sh = trace<false>(L, cull, n, o, sd, path_hit, gp, gn, n_phase2, lane, nullptr, use_masks, cell);
-#endif
-                    is_lit = sh.i < 0;
-                    // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the
-                    // blocker point NUDGED 1e-6 back along the ray (TRT.c:871-874, :939-942): (D - 1e-6)^2 up to ~1e-14 relative
-                    // rounding, where D^2 = sh.d2 (1 +- 4u).  From D <= (D^2+1)/2:
-                    //     (D-1e-6)^2 (1-1e-14)  >=  sh.d2 (1 - 1.01e-6) - 1.01e-6      and, for D >= 1e-5,   (D-1e-6)^2 (1+1e-14) < sh.d2.
-                    // Outside that band the answer is certain without normalising anything; inside it (about one ray in 1e5)
-                    // the exact nudged point is formed as the reference does.
-                    const bool surely_lit = light_d2 < sh.d2 * (1.0 - 1.01e-6) - 1.01e-6;
-                    const bool surely_dark = sh.d2 > 1e-10 && light_d2 >= sh.d2;
-                    if (sh.i >= 0)
-                        is_lit = surely_lit;
-                    if (__any(path_hit && sh.i >= 0 && !surely_lit && !surely_dark))
-                    {
-                        const d3 to_blocker = sub(add(sh.p, scale(unit(sub(o, sh.p)), 0.000001)), o);
-                        if (sh.i >= 0 && !surely_lit && !surely_dark)
-                            is_lit = light_d2 < dot(to_blocker, to_blocker);
-                    }
-                    factor = strength * min1(dot(h_normal, sd));
-                    TRT_STAMP_AT(19); // point shadow tail
-                }
-                if (path_hit && is_lit)
-                    lit = add(lit, mulc(scale(lcolor, factor), load3(L.mat + h_mat * 5)));
-            }
-        }
+        const d3 lit = shadow_stage<COUNT>(L, cull, grids, n, nd, nl, o, h_normal, h_mat, path_hit, gp, gn, tally);
 
         TRT_STAMP_AT(20); // lit accumulate
         // ======================================= END of the bounce =======================================
@@ -560,18 +726,65 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
 
     if (COUNT && f.counters)
     {
-        atomicAdd(&f.counters[0], (unsigned long long)n_path);
-        atomicAdd(&f.counters[1], (unsigned long long)n_shadow);
+        atomicAdd(&f.counters[0], (unsigned long long)tally.path);
+        atomicAdd(&f.counters[1], (unsigned long long)tally.shadow);
         if (lane == 0)
         {
-            atomicAdd(&f.counters[2], (unsigned long long)n_rounds);
-            atomicAdd(&f.counters[3], (unsigned long long)n_phase2);
+            atomicAdd(&f.counters[2], (unsigned long long)tally.rounds);
+            atomicAdd(&f.counters[3], (unsigned long long)tally.phase2);
+            atomicAdd(&f.counters[28], (unsigned long long)tally.swept); // traces in which the wave fell back to the sweep
 #if TRT_STAMP
             for (int i = 0; i < 24; i++)
                 atomicAdd(&f.counters[4 + i], stamp_sum[i]);
 #endif
         }
     }
+}
+
+// trt_probe_rays through the PRODUCTION stages: one lane per ray, the very path_stage / shadow_stage of the render kernel
+// (tables, fall-back sweep, exact tests, lighting).  families[i]: the family ray i is looked up in (trt_raygrid.h; < 0: none,
+// the wave sweeps); nullptr: none for every ray.  Outputs as trace_ray / apply_lighting produce them (TRT.c:793-963).
+__global__ __launch_bounds__(kPersistentBlock) void probe_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids, const double *rays,
+                                                                        const int *families, long count, int *obj, double *point, double *normal,
+                                                                        double *material, double *lit_out)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const LdsImage L = stage_lds_image(lds, s, cull, f, grids);
+    const int n = s.num_spheres, nd = s.num_dir, nl = s.num_dir + s.num_point;
+    const d3 gp = load3(s.ground), gn = load3(s.ground + 3);
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool alive = i < count;
+    const long at = alive ? i : 0;
+    const d3 o = load3(rays + 6 * at), d = load3(rays + 6 * at + 3);
+    int fam = families ? families[at] : -1;
+    Tally tally;
+    const PathHit hit = path_stage<false>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally);
+    const d3 surface = hit.hit ? add(hit.ph.p, scale(hit.back, 0.000001)) : o; // TRT.c:873-874 / :860
+    const d3 lit = shadow_stage<false>(L, cull, grids, n, nd, nl, surface, hit.normal, hit.mat, hit.hit, gp, gn, tally);
+    if (!alive)
+        return;
+    d3 color = d3{0.0, 0.0, 0.0};
+    double refl = 0.0, spec = 0.0; // TRT.c:866: the compound literal zero-fills
+    d3 nrm = hit.back;             // a miss: the (normalised) ray direction, TRT.c:861, :878
+    if (hit.hit)
+    {
+        color = load3(L.mat + hit.mat * 5);
+        refl = L.mat[hit.mat * 5 + 3];
+        spec = L.mat[hit.mat * 5 + 4];
+        nrm = hit.normal;
+    }
+    else
+    {
+        const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, hit.back);
+        color = d3{L.b255[t & 0xFF], L.b255[(t >> 8) & 0xFF], L.b255[(t >> 16) & 0xFF]};
+    }
+    obj[i] = hit.hit ? (hit.ph.i < n ? 1 : 2) : 0;
+    point[3 * i + 0] = surface.x, point[3 * i + 1] = surface.y, point[3 * i + 2] = surface.z;
+    normal[3 * i + 0] = nrm.x, normal[3 * i + 1] = nrm.y, normal[3 * i + 2] = nrm.z;
+    material[5 * i + 0] = color.x, material[5 * i + 1] = color.y, material[5 * i + 2] = color.z;
+    material[5 * i + 3] = refl, material[5 * i + 4] = spec;
+    const d3 c = hit.hit ? d3{clampd(lit.x, 0.0, 1.0), clampd(lit.y, 0.0, 1.0), clampd(lit.z, 0.0, 1.0)} : d3{0.0, 0.0, 0.0}; // TRT.c:960
+    lit_out[3 * i + 0] = c.x, lit_out[3 * i + 1] = c.y, lit_out[3 * i + 2] = c.z;
 }
 
 } // namespace trt

@@ -68,6 +68,9 @@ SYMBOLS = {
     "trt_read_diagnostics": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "trt_set_kernel": (_I, [_VP, _I]),
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
+    "trt_set_path_grids": (_I, [_VP, _I, _I]),
+    "trt_read_path_tables": (C.c_long, [_VP, C.POINTER(L.Camera), _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_long)]),
+    "trt_read_sweep_fallbacks": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
     "trt_reserve_cus": (_I, [_VP, _I]),
     "trt_get_stream": (_I, [_VP, C.POINTER(C.c_void_p)]),
     "trt_selftest_unit": (_I, [_VP, _VP, C.c_size_t, _VP, _VP]),
@@ -75,6 +78,7 @@ SYMBOLS = {
     "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
     "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
     "trt_probe_rays": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
+    "trt_probe_rays_production": (_I, [_VP, C.POINTER(L.Camera), _VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
     "trt_last_error": (C.c_char_p, []),
     "trt_version": (C.c_char_p, []),
 }
@@ -163,6 +167,29 @@ class Context:
         """cells per side of the light-space candidate tables; 0, 0 = off (trt_set_light_grids)"""
         _check(lib().trt_set_light_grids(self._h, directional_cells, point_cells))
 
+    def set_path_grids(self, eye_cells, sphere_cells):
+        """cells per cube-map face side of the path rays' family tables; 0, 0 = off (trt_set_path_grids)"""
+        _check(lib().trt_set_path_grids(self._h, eye_cells, sphere_cells))
+
+    def read_path_tables(self, camera_array):
+        """(info dict, list cells uint64[], pool uint64[]) of the path rays' tables as built for this camera's eye"""
+        cam = camera_struct(camera_array)
+        info = (C.c_long * 8)()
+        probe = np.zeros(1, dtype=np.uint64)
+        lib().trt_read_path_tables(self._h, C.byref(cam), probe.ctypes.data, 0, probe.ctypes.data, 0, info)  # sizes only
+        cells = np.zeros(max(1, info[4]), dtype=np.uint64)
+        pool = np.zeros(max(1, info[7]), dtype=np.uint64)
+        got = lib().trt_read_path_tables(self._h, C.byref(cam), cells.ctypes.data, cells.size, pool.ctypes.data, pool.size, info)
+        if got < 0:
+            _check(int(got))
+        keys = ("enabled", "eye_cells", "sphere_cells", "spheres", "cells", "pool_used_scene", "pool_used_eye", "pool_capacity")
+        return dict(zip(keys, [int(x) for x in info])), cells[:got], pool
+
+    def read_sweep_fallbacks(self):
+        v = C.c_ulonglong()
+        _check(lib().trt_read_sweep_fallbacks(self._h, C.byref(v)))
+        return v.value
+
     def selftest_unit(self, xyzw):
         """(fast, reference): unit(x,y,z) and sqrt(w) by the kernels' lean code and by the compiler's plain expansions"""
         v = np.ascontiguousarray(xyzw, dtype=np.float64).reshape(-1, 4)
@@ -223,7 +250,7 @@ class Context:
     def read_diagnostics(self):
         t, p = C.c_ulonglong(), C.c_ulonglong()
         _check(lib().trt_read_diagnostics(self._h, C.byref(t), C.byref(p)))
-        return {"wave_loop_trips": t.value, "phase2_rounds": p.value}
+        return {"wave_loop_trips": t.value, "phase2_rounds": p.value, "swept_traces": self.read_sweep_fallbacks()}
 
     def kernel_info(self):
         v = [_I() for _ in range(5)]
@@ -245,6 +272,19 @@ class Context:
         point, normal, material, lit = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 5)), np.zeros((n, 3))
         _check(lib().trt_probe_rays(self._h, rays.ctypes.data, n, obj.ctypes.data, point.ctypes.data,
                                     normal.ctypes.data, material.ctypes.data, lit.ctypes.data))
+        return obj, point, normal, material, lit
+
+
+    def probe_rays_production(self, camera_array, rays, families=None):
+        """trt_probe_rays_production: the probe through the production kernel's stages (tables, sweep, exact tests, lighting)"""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = rays.shape[0]
+        fam = None if families is None else np.ascontiguousarray(families, dtype=np.int32)
+        obj = np.zeros(n, dtype=np.int32)
+        point, normal, material, lit = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 5)), np.zeros((n, 3))
+        cam = camera_struct(camera_array)
+        _check(lib().trt_probe_rays_production(self._h, C.byref(cam), rays.ctypes.data, None if fam is None else fam.ctypes.data, n,
+                                               obj.ctypes.data, point.ctypes.data, normal.ctypes.data, material.ctypes.data, lit.ctypes.data))
         return obj, point, normal, material, lit
 
 

@@ -66,6 +66,42 @@ def test_single_rays_match_reference_vectors(ctx):
     assert np.array_equal(bits(lit[hit]), bits(d["lit"][hit]))
 
 
+def _same_probe(got, want, hit_only_lit=True):
+    obj, point, normal, material, lit = got
+    assert np.array_equal(obj, want["obj"])
+    assert np.array_equal(bits(point), bits(want["point"]))
+    assert np.array_equal(bits(normal), bits(want["normal"]))
+    assert np.array_equal(bits(material), bits(want["material"]))
+    hit = obj != 0
+    assert np.array_equal(bits(lit[hit]), bits(want["lit"][hit]))
+
+
+@pytest.mark.parametrize("grids", [(64, 16), (5, 3), (0, 0)], ids=["default_tables", "coarse_tables", "sweep_only"])
+def test_production_stages_match_reference_single_ray_vectors(ctx, grids):
+    """trace_ray, ray_intersects_sphere/plane, get_skybox_color and apply_lighting (TRT.c:638-963), each through the code that
+    SHIPS: the probe runs the render kernel's own path_stage / shadow_stage.  (a) the 600 arbitrary rays of rays.npz (no
+    family: every wave sweeps; non-unit directions among them); (b) chains of path rays as project_scene produces them, every
+    ray looked up in the table of its family -- eye, mirror eye, spheres, mirror spheres -- 64 spheres with mirrors and 256."""
+    try:
+        ctx.set_path_grids(*grids)
+        d = np.load(T.GOLDEN + "/rays.npz")
+        scene = S.SceneData.from_arrays(d, T.sky("uv_checker"), prefix="scene/")
+        ctx.set_scene(scene)
+        _same_probe(ctx.probe_rays_production(scene.camera, d["rays"]), d)
+        fam = np.load(T.GOLDEN + "/rays_families.npz")
+        for tag in ("a", "b"):
+            scene = S.SceneData.from_arrays(fam, T.sky("uv_checker"), prefix=tag + "/scene/")
+            want = {k: fam[f"{tag}/{k}"] for k in ("obj", "point", "normal", "material", "lit")}
+            ctx.set_scene(scene)
+            _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], fam[tag + "/families"]), want)
+            # a WRONG family must not matter either: the membership test sends such rays to the sweep
+            wrong = np.roll(fam[tag + "/families"], 7)
+            _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], wrong), want)
+            _same_probe(ctx.probe_rays(fam[tag + "/rays"]), want)  # and the reference-order kernel's probe
+    finally:
+        ctx.set_path_grids(64, 16)
+
+
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("case", SMALL, ids=[c["name"] for c in SMALL])
 def test_frame_matches_reference_golden(ctx, case, kernel):
@@ -442,6 +478,101 @@ def test_light_space_tables_never_change_a_frame(ctx, cells):
             assert np.array_equal(bits(got), bits(want)), (cells, len(scene.spheres))
     finally:
         ctx.set_light_grids(128, 64)
+
+
+def _decode_cells(cells, pool):
+    """list cells (csrc/trt_raygrid.h) -> list of tuples of sphere indices; None for a cell without a list"""
+    out = []
+    for c in cells.tolist():
+        ctl = c >> 56
+        if ctl == 0xFF:
+            out.append(None)
+        elif ctl & 0x80:
+            count, at = (c >> 32) & 0xFFFF, c & 0xFFFFFFFF
+            out.append(tuple((int(pool[at + (k >> 3)]) >> (8 * (k & 7))) & 0xFF for k in range(count)))
+        else:
+            out.append(tuple((c >> (8 * k)) & 0xFF for k in range(ctl)))
+    return out
+
+
+@pytest.mark.parametrize("cells", [(0, 0), (2, 2), (9, 5), (64, 16), (128, 32)], ids=["off", "coarsest", "odd", "default", "fine"])
+def test_path_ray_tables_never_change_a_frame(ctx, cells):
+    """A path ray's candidate spheres come from the direction table of its family (csrc/trt_raygrid.h): the eye, its mirror
+    image in the ground, the sphere it starts on, that sphere's mirror image.  Whatever the tables' resolution -- or with them
+    off, every path ray sweeping -- frames must equal the oracle bit for bit and the trace counts the reference's: 64 and 256
+    spheres, mirror-heavy materials (long chains of families), a tilted ground with a non-unit normal, a perfect-mirror
+    floor, the eye inside a sphere, touching / nested / duplicated / huge / tiny spheres, a moving eye (tables rebuilt)."""
+    import test_raygrid as R
+    cases = [(S.synth_scene(64, T.sky("synth"), T.bench_camera(96, 54)), 96, 54, 8, 10),
+             (S.synth_scene(256, T.sky("synth"), T.bench_camera(64, 36, 2.5)), 64, 36, 12, 4),
+             (S.synth_scene(64, T.sky("synth"), T.bench_camera(64, 36, 10.0), mirror_fraction=0.5), 64, 36, 8, 5)]
+    cases += [(scene, 64, 36, 8, 3) for _, scene in R._odd_scenes()[1:]]
+    base = S.synth_scene(64, T.sky("synth"), T.bench_camera(48, 27))
+    cases += [(base.with_camera(T.bench_camera(48, 27, t)), 48, 27, 6, 2) for t in (0.0, 0.5, 33.3)]  # same spheres, the eye moves
+    try:
+        ctx.set_path_grids(*cells)
+        ctx.enable_counters(True)
+        for scene, w, h, b, spp in cases:
+            with np.errstate(all="ignore"):
+                want, st = T.oracle_render(scene, w, h, b, spp)
+            got = render(ctx, scene, w, h, b, spp)
+            assert np.array_equal(bits(got), bits(want)), (cells, len(scene.spheres))
+            assert ctx.read_counters() == (st.path_rays, st.shadow_rays)
+    finally:
+        ctx.enable_counters(False)
+        ctx.set_path_grids(64, 16)
+
+
+def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
+    """The library forms the families' cones and marks and packs the cells on the GPU; tests/test_raygrid.py proves the HOST
+    builder conservative.  Both run the same predicates (+ - * / sqrt only), so every cell must list the same spheres."""
+    import test_raygrid as R
+    lib = R.build_checker()
+    base = S.synth_scene(40, T.sky("synth"), T.bench_camera(32, 18, 10.0), seed=5)
+    g = base.ground.copy()
+    g[0:6] = [0.3, -1.25, 0.2, 0.1, 2.0, -0.2]
+    scenes = [S.synth_scene(64, T.sky("synth"), T.bench_camera(32, 18)), S.synth_scene(256, T.sky("synth"), T.bench_camera(32, 18, 2.5)),
+              S.SceneData(base.spheres, g, base.dir_lights, base.point_lights, base.camera, base.sky), R._odd_scenes()[4][1]]
+    try:
+        for scene in scenes:
+            for ge, gs in ((64, 16), (11, 3)):
+                ctx.set_path_grids(ge, gs)
+                ctx.set_scene(scene)
+                info, cells, pool = ctx.read_path_tables(scene.camera)
+                n = len(scene.spheres)
+                assert info["enabled"] == 1 and info["cells"] == 2 * 6 * ge * ge + 2 * n * 6 * gs * gs == len(cells)
+                sph = np.ascontiguousarray(scene.spheres, dtype=np.float64)
+                ground = np.ascontiguousarray(scene.ground, dtype=np.float64)
+                eye = np.ascontiguousarray(scene.camera[9:12], dtype=np.float64)
+                want_cells = np.zeros(len(cells), dtype=np.uint64)
+                want_pool = np.zeros(len(cells) + 16, dtype=np.uint64)
+                used = lib.raygrid_host_cells(sph.ctypes.data, n, ground.ctypes.data, eye.ctypes.data, ge, gs, want_cells.ctypes.data,
+                                              want_pool.ctypes.data, len(want_pool))
+                assert 0 <= used <= len(want_pool)
+                got, want = _decode_cells(cells, pool), _decode_cells(want_cells, want_pool)
+                # a pool too small for the long lists of a very coarse table leaves some cells without a list (their rays
+                # sweep); WHICH cells depends on the order the cells reserved their words in: compare the others
+                bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b and a is not None and b is not None]
+                assert not bad, (n, ge, gs, len(bad), bad[:3], [got[i] for i in bad[:3]], [want[i] for i in bad[:3]])
+                if ge == 64:  # the library's resolutions: every cell has its list
+                    assert None not in got and None not in want
+    finally:
+        ctx.set_path_grids(64, 16)
+
+
+def test_the_tables_serve_nearly_every_trace(ctx):
+    """The sweep over all spheres is only the fall-back: on the north-star scene fewer than 2 % of the wave-level traces may
+    take it (rays beyond a table's range: ground points near the horizon)."""
+    scene = S.synth_scene(64, T.sky("synth"), T.bench_camera(480, 270))
+    ctx.enable_counters(True)
+    try:
+        render(ctx, scene, 480, 270, 8, 10)
+        path, shadow = ctx.read_counters()
+        diag = ctx.read_diagnostics()
+    finally:
+        ctx.enable_counters(False)
+    traces = diag["wave_loop_trips"] * 3  # one path trace and two shadow stages per round, at most
+    assert 0 <= diag["swept_traces"] < 0.02 * traces, diag
 
 
 def test_device_built_light_tables_equal_the_host_reference_builder(ctx):
