@@ -151,7 +151,7 @@ int trt_set_light_grids(trt_context *ctx, int directional_cells, int point_cells
  * 6 * cells^2 direction cells listing the spheres its rays can touch; a path ray reads ONE cell instead of sweeping all
  * spheres (TRT.c:805-828 tests every sphere).  eye_cells: per face side for the two families of the eye (rebuilt on the GPU
  * when the eye moves), sphere_cells: for the 2N families of the spheres (rebuilt when spheres or ground change).
- * 0, 0 turns them off (every path ray sweeps); frames are bit-identical either way.  Defaults 64 and 16; environment
+ * 0, 0 turns them off (every path ray sweeps); frames are bit-identical either way.  Defaults 64 and 32; environment
  * TRT_PATHGRID="e,s" overrides the defaults.  Scenes with more than 256 spheres render without any candidate table. */
 int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_cells);
 

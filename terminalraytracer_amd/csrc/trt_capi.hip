@@ -30,7 +30,7 @@
 #define TRT_PATHGRID_EYE 64
 #endif
 #ifndef TRT_PATHGRID_SPHERE
-#define TRT_PATHGRID_SPHERE 16
+#define TRT_PATHGRID_SPHERE 32
 #endif
 
 #include "trt_common.hpp"

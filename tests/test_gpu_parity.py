@@ -76,7 +76,7 @@ def _same_probe(got, want, hit_only_lit=True):
     assert np.array_equal(bits(lit[hit]), bits(want["lit"][hit]))
 
 
-@pytest.mark.parametrize("grids", [(64, 16), (5, 3), (0, 0)], ids=["default_tables", "coarse_tables", "sweep_only"])
+@pytest.mark.parametrize("grids", [(64, 32), (5, 3), (0, 0)], ids=["default_tables", "coarse_tables", "sweep_only"])
 def test_production_stages_match_reference_single_ray_vectors(ctx, grids):
     """trace_ray, ray_intersects_sphere/plane, get_skybox_color and apply_lighting (TRT.c:638-963), each through the code that
     SHIPS: the probe runs the render kernel's own path_stage / shadow_stage.  (a) the 600 arbitrary rays of rays.npz (no
@@ -99,7 +99,7 @@ def test_production_stages_match_reference_single_ray_vectors(ctx, grids):
             _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], wrong), want)
             _same_probe(ctx.probe_rays(fam[tag + "/rays"]), want)  # and the reference-order kernel's probe
     finally:
-        ctx.set_path_grids(64, 16)
+        ctx.set_path_grids(64, 32)
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
@@ -495,7 +495,7 @@ def _decode_cells(cells, pool):
     return out
 
 
-@pytest.mark.parametrize("cells", [(0, 0), (2, 2), (9, 5), (64, 16), (128, 32)], ids=["off", "coarsest", "odd", "default", "fine"])
+@pytest.mark.parametrize("cells", [(0, 0), (2, 2), (9, 5), (64, 32), (128, 48)], ids=["off", "coarsest", "odd", "default", "fine"])
 def test_path_ray_tables_never_change_a_frame(ctx, cells):
     """A path ray's candidate spheres come from the direction table of its family (csrc/trt_raygrid.h): the eye, its mirror
     image in the ground, the sphere it starts on, that sphere's mirror image.  Whatever the tables' resolution -- or with them
@@ -520,7 +520,7 @@ def test_path_ray_tables_never_change_a_frame(ctx, cells):
             assert ctx.read_counters() == (st.path_rays, st.shadow_rays)
     finally:
         ctx.enable_counters(False)
-        ctx.set_path_grids(64, 16)
+        ctx.set_path_grids(64, 32)
 
 
 def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
@@ -535,7 +535,7 @@ def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
               S.SceneData(base.spheres, g, base.dir_lights, base.point_lights, base.camera, base.sky), R._odd_scenes()[4][1]]
     try:
         for scene in scenes:
-            for ge, gs in ((64, 16), (11, 3)):
+            for ge, gs in ((64, 32), (11, 3)):
                 ctx.set_path_grids(ge, gs)
                 ctx.set_scene(scene)
                 info, cells, pool = ctx.read_path_tables(scene.camera)
@@ -557,7 +557,7 @@ def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
                 if ge == 64:  # the library's resolutions: every cell has its list
                     assert None not in got and None not in want
     finally:
-        ctx.set_path_grids(64, 16)
+        ctx.set_path_grids(64, 32)
 
 
 def test_the_tables_serve_nearly_every_trace(ctx):

@@ -78,7 +78,8 @@ FRAMES = [("north-star scene, 64 spheres", lambda: S.synth_scene(64, T.sky("synt
 def test_path_tables_hold_every_exact_hit_on_real_frames(checker, name, make, w, h, b):
     scene = make()
     rays, kinds = traced_rays(scene, w, h, b, 10)
-    for g_eye, g_sph in ((64, 16), (7, 3)):
+    # the library's default resolution (64 / 32; 64 / 16 for the 256-sphere scene, whose host build would take a minute) and a very coarse one
+    for g_eye, g_sph in ((64, 32 if len(scene.spheres) <= 64 else 16), (7, 3)):
         st = run(checker, scene, rays, kinds, g_eye, g_sph)
         print(f"\n{name} g {g_eye}/{g_sph}: {describe(st)}")
         assert st.rays == int((kinds == 0).sum()) and st.violations == 0, list(st.first_violation)

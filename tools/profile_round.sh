@@ -1,11 +1,23 @@
+# The round's evidence in one go (run on the GPU box through gpurun): bench lines, rocprofv3 kernel stats at one and two
+# frames in flight, PMC passes (HBM traffic in separate FETCH_SIZE / WRITE_SIZE passes as MI355X_MICROARCH.md prescribes).
+# usage: bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...
 set -e
+tag=${1:-prof}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout -k 10 300 python3 bench.py > gpurun_out/h_bench.json
-timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --stats -d gpurun_out/h_stats_d1 -o h -- python3 bench.py --no-cpu-baseline --depth 1 > gpurun_out/h_bench_d1_prof.json
-timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d gpurun_out/h_fetch -o h -- python3 bench.py --no-cpu-baseline --depth 1 --steps 4 --warmup 1 > /dev/null
-timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d gpurun_out/h_write -o h -- python3 bench.py --no-cpu-baseline --depth 1 --steps 4 --warmup 1 > /dev/null
-timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES -d gpurun_out/h_sq -o h -- python3 bench.py --no-cpu-baseline --depth 1 --steps 4 --warmup 1 > /dev/null
-timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d gpurun_out/h_sq2 -o h -- python3 bench.py --no-cpu-baseline --depth 1 --steps 4 --warmup 1 > /dev/null
-find gpurun_out/h_* -name "*.csv" | head -40
+O=gpurun_out/$tag
+mkdir -p $O
+timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 300 python3 bench.py --animation 60 --no-cpu-baseline > $O/bench_anim.json 2> $O/bench_anim.err
+B="python3 bench.py --no-cpu-baseline --no-verify"
+timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_d1 -o p -- $B --depth 1 > $O/bench_d1_prof.json
+timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_d2 -o p -- $B > $O/bench_d2_prof.json
+S="--depth 1 --steps 4 --warmup 1"
+timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- $B $S > /dev/null
+timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p -- $B $S > /dev/null
+timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES -d $O/pmc_sq -o p -- $B $S > /dev/null
+timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_sq2 -o p -- $B $S > /dev/null
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_sq2 --json $O/pmc_summary.json > $O/pmc_summary.txt
+find $O -name "*kernel_stats.csv" | head
+cat $O/pmc_summary.txt | grep -v "<true>"
