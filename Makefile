@@ -31,12 +31,17 @@ $(BUILD)/trt_capi$(subst =,_,$(subst -D,_,$(TUNE))).o: $(CSRC)/trt_capi.hip $(wi
 	@grep -E "error|warning:" $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt || true
 	@awk '/Function Name: .*render_rounds_kernelILb0/ {f=1} f && /VGPRs:/ {split($$0,a,"VGPRs: "); v=a[2]+0; print "render_rounds_kernel<false>: " v " VGPRs" (v>128 ? "  ** WARNING: more than 128 -> 3 waves/SIMD **" : " (4 waves/SIMD)"); exit}' $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt
 
-$(LIB): $(BUILD)/trt_capi$(subst =,_,$(subst -D,_,$(TUNE))).o $(HOST_OBJ)
-	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $< $(HOST_OBJ)
+$(BUILD)/trt_dist.o: $(CSRC)/trt_dist.hip include/trt.h include/trt_hip.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/trt_dist.hip
 
-demo: examples/trt_demo
-examples/trt_demo: examples/trt_demo.c $(LIB) include/trt_hip.h include/trt_host.h
-	$(CC) -O2 -std=c11 -Iinclude -o $@ $< -Lterminalraytracer_amd -ltrt_hip -lm -Wl,-rpath,'$$ORIGIN/../terminalraytracer_amd'
+# RCCL is bound at run time by trt_dist.hip (dlopen): the library does not link against it
+$(LIB): $(BUILD)/trt_capi$(subst =,_,$(subst -D,_,$(TUNE))).o $(BUILD)/trt_dist.o $(HOST_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $< $(BUILD)/trt_dist.o $(HOST_OBJ) -ldl
+
+demo: examples/trt_demo examples/trt_dist_demo
+examples/%: examples/%.c $(LIB) include/trt_hip.h include/trt_host.h
+	$(CC) -O2 -std=gnu11 -Iinclude -o $@ $< -Lterminalraytracer_amd -ltrt_hip -lm -Wl,-rpath,'$$ORIGIN/../terminalraytracer_amd'
 
 oracle:
 	$(MAKE) -C oracle all
@@ -46,5 +51,5 @@ resource-usage:
 	$(HIPCC) $(HIPFLAGS) -shared -Rpass-analysis=kernel-resource-usage -o /tmp/trt_ru.so $(CSRC)/trt_capi.hip 2>&1 | grep -E "remark" || true
 
 clean:
-	rm -rf $(LIB) $(BUILD) examples/trt_demo
+	rm -rf $(LIB) $(BUILD) examples/trt_demo examples/trt_dist_demo
 	$(MAKE) -C oracle clean

@@ -13,7 +13,10 @@ frames/s next to path rays/s.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame is sharded by
 interleaved 8-row tiles across the ranks and assembled on rank 0 with one RCCL gather per
-frame ("scaling": "strong").
+frame ("scaling": "strong").  Row tiles, the RCCL communicator, the gather and the frame pipeline
+live in the library behind the C-ABI (trt_dist_*, include/trt_hip.h section 3): the same calls a C
+host makes; torch.distributed only carries the communicator id to the ranks and times the run.
+--backend gloo selects the PyTorch-level rehearsal path (several ranks sharing one GPU).
 
 metric: path rays/s = trace calls issued by the bounce loop (primary + secondary rays,
 TRT.c:1024) per second.  The per-frame ray count is deterministic; it is taken once from the
@@ -158,6 +161,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
     ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = 2)")
+    ap.add_argument("--tile-rows", type=int, default=8, help="rows per interleaved tile of the row sharding")
     ap.add_argument("--reserve-cus", type=int, default=0, help="compute units kept free of render workgroups so that the gather's kernels can "
                                                               "run beside them (a guess until an 8-GPU run has been made: default 0)")
     args = ap.parse_args()
@@ -189,19 +193,44 @@ def main():
     scene = build_scene(workload)
     cameras = animation_cameras(width, height, args.animation) if args.animation > 0 else [scene.camera]
     camera_of = lambda step: cameras[step % len(cameras)]  # noqa: E731
-    r = HipShardRenderer(scene, width, height, rank, world, local, bounces, SPP, depth=args.depth, reserve_cus=args.reserve_cus)
-    r.for_each_context(lambda c: c.set_kernel(args.kernel))
+    rehearsal = world > 1 and args.backend != "nccl"
+    if rehearsal:  # PyTorch-level sharding over gloo: several ranks may share one GPU, which RCCL cannot do
+        r = HipShardRenderer(scene, width, height, rank, world, local, bounces, SPP, tile_rows=args.tile_rows, depth=args.depth,
+                             reserve_cus=args.reserve_cus)
+        contexts = [slot["ctx"] for slot in r.slots]
+        rowset = r.sharded.rowset
+        render = r.render                                    # -> frame tensor on rank 0
+        fetch = lambda frame: frame.cpu().numpy()            # noqa: E731
+    else:          # the product path: trt_dist_* behind the C-ABI
+        uid = None
+        if world > 1:
+            box = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local}")
+            if rank == 0:
+                box.copy_(torch.frombuffer(bytearray(hip.dist_unique_id()), dtype=torch.uint8))
+            dist.broadcast(box, 0)
+            uid = bytes(box.cpu().numpy().tobytes())
+        r = hip.Dist(local, scene, uid, rank, world, width, height, tile_rows=args.tile_rows, frames_in_flight=args.depth,
+                     reserved_cus=args.reserve_cus)
+        contexts = [r.context(i) for i in range(args.depth)]
+        rowset = hip.RowSet.shard(width, height, rank, world, args.tile_rows)
+        render = lambda cam: r.render(cam, bounces, SPP)     # noqa: E731  -> device address of the frame on rank 0
+        fetch = r.fetch
+    for c in contexts:
+        c.set_kernel(args.kernel)
+    ctx0 = contexts[0]
+    local_rows = hip.lib().trt_rowset_rows(C.byref(rowset))
+    scratch = torch.zeros(max(1, local_rows) * width * 3, dtype=torch.float64, device=f"cuda:{local}")  # for the untimed passes
 
     # untimed: ray counts of this rank's rows for every distinct camera (counting variant of the kernel)
-    r.ctx.enable_counters(True)
+    ctx0.enable_counters(True)
     path_per_cam, shadow_per_cam, diag = [], [], None
     for cam in cameras:
-        r.ctx.render_device(cam, r.sharded.rowset, bounces, SPP, r.slots[0]["pixels"].data_ptr(), r.slots[0]["pixels"].numel() * 8)
-        p, s = r.ctx.read_counters()
+        ctx0.render_device(cam, rowset, bounces, SPP, scratch.data_ptr(), scratch.numel() * 8)
+        p, s = ctx0.read_counters()
         path_per_cam.append(p)
         shadow_per_cam.append(s)
-        diag = diag or r.ctx.read_diagnostics()
-    r.ctx.enable_counters(False)
+        diag = diag or ctx0.read_diagnostics()
+    ctx0.enable_counters(False)
     torch.cuda.synchronize()
     counts = torch.tensor([path_per_cam, shadow_per_cam], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
@@ -218,33 +247,32 @@ def main():
     # untimed: strictly one frame at a time on ONE context, every launch bracketed by HIP events on its stream; the render
     # kernel's own duration (the roofline's denominator) and the ordered-mean kernel's behind it
     d1 = min(args.steps, 20)
-    px0 = r.slots[0]["pixels"]
     for i in range(2 + d1):
-        r.ctx.render_device(camera_of(i), r.sharded.rowset, bounces, SPP, px0.data_ptr(), px0.numel() * 8)
-        r.ctx.synchronize()
-    render_ms, reduce_ms = r.ctx.render_kernel_times(d1)
+        ctx0.render_device(camera_of(i), rowset, bounces, SPP, scratch.data_ptr(), scratch.numel() * 8)
+        ctx0.synchronize()
+    render_ms, reduce_ms = ctx0.render_kernel_times(d1)
     render_ms_avg, reduce_ms_avg = float(np.mean(render_ms)), float(np.mean(reduce_ms))
     barrier()
 
     if args.check:  # the sharded, gathered frame must equal the frame of one renderer, bit for bit
-        frame = r.render(scene.camera)
+        frame = render(scene.camera)
         torch.cuda.synchronize()
         if rank == 0:
             with hip.Context(local) as single:
                 single.set_scene(scene)
                 whole = single.render_host(scene.camera, hip.RowSet.whole(width, height), bounces, SPP)
-            same = np.array_equal(frame.cpu().numpy().view(np.uint64), whole.view(np.uint64))
+            same = np.array_equal(fetch(frame).view(np.uint64), whole.view(np.uint64))
             print(f"CHECK sharded({world}) == single: {same}", file=sys.stderr)
             assert same
         barrier()
 
     for i in range(args.warmup):
-        r.render(camera_of(i))
+        render(camera_of(i))
     barrier()
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
-        last = r.render(camera_of(i))
+        last = render(camera_of(i))
     barrier()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
@@ -254,19 +282,18 @@ def main():
     # untimed: the frame the timed loop produced last (and, for the animation, frame 59) against the GENUINE reference's hash
     verified, checks = None, []
     if not args.no_verify:
-        probes = [((args.steps - 1) % len(cameras), last)]
+        probes = [((args.steps - 1) % len(cameras), False)]
         if args.animation > 59 and (args.steps - 1) % len(cameras) != 59:
-            probes.append((59, None))
-        for index, frame in probes:
+            probes.append((59, True))
+        for index, again in probes:
             key = index if args.animation > 0 else 1.0
             if key not in wl["golden"]:
                 continue
-            if frame is None:
-                frame = r.render(cameras[index])
+            frame = render(cameras[index]) if again else last  # a collective: every rank renders, rank 0 gets the frame
             torch.cuda.synchronize()
             if rank == 0:
                 want = golden_hash(wl["golden"][key])
-                got = host.fnv1a64(frame.cpu().numpy())
+                got = host.fnv1a64(fetch(frame))
                 checks.append({"frame": wl["golden"][key], "fnv": got, "reference_fnv": want["fb_fnv"], "ok": got == want["fb_fnv"]})
             barrier()
         if rank == 0:
@@ -274,7 +301,7 @@ def main():
 
     if rank == 0:
         ms_step = seconds / args.steps * 1e3
-        rows = hip.lib().trt_rowset_rows(C.byref(r.sharded.rowset))
+        rows = local_rows
         nd, npt = scene.dir_lights.shape[0], scene.point_lights.shape[0]
         alg = algorithmic_bytes(width, rows, wl["spheres"], SKY_DIM, nd, npt)
         achieved = alg / (render_ms_avg * 1e-3) / 1e9
@@ -288,7 +315,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl["text"], "sharding": f"{world} x interleaved 8-row tiles, 1 gather/frame",
+            "config": {"workload": wl["text"], "sharding": f"{world} x interleaved {args.tile_rows}-row tiles, 1 gather/frame",
+                       "multi_gpu_path": "PyTorch-level rehearsal (gloo)" if rehearsal else "C-ABI trt_dist_* (RCCL send/recv gather inside the library)",
                        "kernel": {0: "persistent waves, synchronous rounds", 1: "reference-order"}[args.kernel],
                        "frames_in_flight": args.depth, "reserved_cus": args.reserve_cus},
             "frames_per_s": args.steps / seconds,
@@ -310,7 +338,7 @@ def main():
                                  "~1 algorithmic byte per ray, frac << 1 by nature (SURVEY 0, DESIGN.md 5); `traffic` and `valu` are "
                                  "COMMITTED rocprofv3 PMC results (profiles/traffic.json), not measured in this run"},
             "valu": (prof or {}).get("valu"),
-            "kernel_info": r.ctx.kernel_info(),
+            "kernel_info": ctx0.kernel_info(),
             # one round = one path ray per lane (+ one shadow ray per light for the lanes that hit something)
             "diagnostics": dict(diag, path_lane_utilisation=path_per_cam[0] / max(1, 64 * diag["wave_loop_trips"]),
                                 shadow_lane_utilisation=shadow_per_cam[0] / max(1, 64 * diag["wave_loop_trips"] * max(1, nd + npt)),

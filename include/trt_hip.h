@@ -203,6 +203,42 @@ int trt_probe_rays_production(trt_context *ctx, const Camera *camera, const Ray 
 const char *trt_last_error(void);
 const char *trt_version(void);
 
+/* ---- 3. one frame over the GPUs of a node (csrc/trt_dist.hip) --------------------------------- */
+
+/* The reference renders a frame with one call, project_scene (TRT.c:966), from its single call site TRT.c:1339; every
+ * pixel is independent.  Here one rank = one process (or thread) = one GPU; the ranks render interleaved tiles of
+ * `tile_rows` rows each (tile t -> rank t mod world) and ONE gather per frame brings the rows to rank 0 over RCCL
+ * (ncclSend / ncclRecv inside one group on the library's own stream; over xGMI every peer has its own link to the root).
+ * Frames are pipelined over `frames_in_flight` renderer contexts.  RCCL is loaded at run time and only for world > 1.
+ * The host program carries the 128-byte id from rank 0 to the other ranks however it likes (MPI, a file, a socket,
+ * torch.distributed): it is what ncclGetUniqueId produced. */
+typedef struct trt_dist trt_dist;
+#define TRT_DIST_ID_BYTES 128
+
+int trt_dist_unique_id(void *id_out); /* rank 0 */
+
+/* Collective over the `world` ranks (same id, world, frame size, tile_rows everywhere).  scene: as for trt_set_scene (host
+ * pointers inside; every rank holds the whole scene, ~1.5 MB with a 256^2 cubemap).  reserved_cus: compute units the
+ * renderers leave to the collective's kernels (trt_reserve_cus; 0 = none).  id may be NULL when world == 1 (RCCL is then
+ * not touched at all; with an id a one-rank communicator is created and the gather path runs with nobody to receive from). */
+int trt_dist_create(int device, const Scene *scene, const void *id, int rank, int world, int width, int height, int tile_rows,
+                    int frames_in_flight, int reserved_cus, trt_dist **out);
+int trt_dist_set_scene(trt_dist *d, const Scene *scene);
+
+/* Collective, asynchronous: this rank's rows of the frame seen from `camera` (TRT.c:1327-1339: a new camera per frame),
+ * then the gather.  On rank 0 *d_frame is the DEVICE address of the assembled frame, height x width x 3 doubles in the
+ * Screen layout of TRT.c:188-193 (NULL on the other ranks); it is complete after trt_dist_synchronize and is reused
+ * `frames_in_flight` calls later. */
+int trt_dist_render(trt_dist *d, const Camera *camera, int bounce_limit, int rays_per_pixel, void **d_frame);
+int trt_dist_synchronize(trt_dist *d);
+/* synchronise, then copy an assembled frame into screen->pixels-like host memory (width*height Vectors) */
+int trt_dist_fetch(trt_dist *d, const void *d_frame, Vector *pixels);
+int trt_dist_info(const trt_dist *d, int *rank, int *world, int *local_rows, int *max_rows, int *frames_in_flight);
+/* the renderer context of a slot (counters, kernel times, kernel selection); owned by d */
+trt_context *trt_dist_context(trt_dist *d, int slot);
+int trt_dist_destroy(trt_dist *d);
+const char *trt_dist_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

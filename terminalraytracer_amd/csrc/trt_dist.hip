@@ -1,0 +1,422 @@
+// trt_dist.hip -- one frame sharded over the GPUs of a node, behind the C-ABI (include/trt_hip.h, section 3).
+//
+// The frame producer is embarrassingly parallel over pixels; the only exchange is assembling the
+// framebuffer.  One trt_dist per rank (one process -- or thread -- per GPU).  Rows are dealt in interleaved tiles of
+// `tile_rows` rows (tile t -> rank t mod world, trt_rowset) so that sky rows and sphere / floor rows, which differ ~10x in
+// cost, spread evenly.  Per frame every rank renders its tiles into a compact shard buffer on the stream of one of its
+// `depth` renderer contexts, then ONE gather brings the shards to rank 0: ncclSend on the peers, `world - 1` ncclRecv on
+// the root inside one ncclGroupStart/End, all on the communicator's own stream (RCCL over xGMI: each peer sends over its
+// own direct link to the root, so the gather is not ring-bound), and one small kernel on the root puts the rows into frame
+// order.  Frames are pipelined: frame f + 1 renders on the next context while frame f is gathered; a slot renders again
+// only after its previous gather has been enqueued (events, no host waits).  The per-frame host work is this file's
+// trt_dist_render: a handful of launches and event calls.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1; a process that already carries one -- PyTorch bundles its own -- keeps
+// using that one), so libtrt_hip.so itself does not depend on it and single-GPU hosts never load it.
+#include "trt_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace
+{
+
+thread_local char g_dist_error[512] = "";
+
+int dist_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_dist_error, sizeof g_dist_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define DIST_HIP(expr)                                                                                             \
+    do                                                                                                             \
+    {                                                                                                              \
+        hipError_t e_ = (expr);                                                                                    \
+        if (e_ != hipSuccess)                                                                                      \
+            return dist_fail(TRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// the eight RCCL entry points used, bound by name
+struct Rccl
+{
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    char why[256] = "";
+};
+
+Rccl *rccl()
+{
+    static Rccl lib;
+    static bool tried = false;
+    if (tried)
+        return lib.handle ? &lib : nullptr;
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *name : names)
+        if ((lib.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+            break;
+    if (!lib.handle)
+    {
+        snprintf(lib.why, sizeof lib.why, "%s", dlerror());
+        return nullptr;
+    }
+    bool ok = true;
+    auto bind = [&](const char *symbol) {
+        void *p = dlsym(lib.handle, symbol);
+        ok = ok && p;
+        return p;
+    };
+    lib.GetUniqueId = (decltype(lib.GetUniqueId))bind("ncclGetUniqueId");
+    lib.CommInitRank = (decltype(lib.CommInitRank))bind("ncclCommInitRank");
+    lib.CommDestroy = (decltype(lib.CommDestroy))bind("ncclCommDestroy");
+    lib.GroupStart = (decltype(lib.GroupStart))bind("ncclGroupStart");
+    lib.GroupEnd = (decltype(lib.GroupEnd))bind("ncclGroupEnd");
+    lib.Send = (decltype(lib.Send))bind("ncclSend");
+    lib.Recv = (decltype(lib.Recv))bind("ncclRecv");
+    lib.GetErrorString = (decltype(lib.GetErrorString))bind("ncclGetErrorString");
+    if (!ok)
+    {
+        snprintf(lib.why, sizeof lib.why, "librccl lacks an entry point");
+        lib.handle = nullptr;
+        return nullptr;
+    }
+    return &lib;
+}
+
+const char *rccl_why() { return "librccl.so.1 could not be loaded or lacks an entry point (multi-GPU needs RCCL)"; }
+
+#define DIST_NCCL(R, expr)                                                                                          \
+    do                                                                                                              \
+    {                                                                                                               \
+        ncclResult_t r_ = (expr);                                                                                   \
+        if (r_ != ncclSuccess)                                                                                      \
+            return dist_fail(TRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// rows of the rank-major, padded gather buffer -> frame order: one thread per double
+__global__ void assemble_rows_kernel(const double *gathered, const int *source_row, double *frame, long row_doubles, long total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total)
+        return;
+    const long row = i / row_doubles, at = i - row * row_doubles;
+    frame[i] = gathered[(long)source_row[row] * row_doubles + at];
+}
+
+struct Slot
+{
+    trt_context *ctx = nullptr;
+    hipStream_t stream = nullptr; // the context's own
+    double *shard = nullptr;      // this rank's rows (padded to the largest shard); on the root a view into `gathered`
+    double *gathered = nullptr;   // root: world x max_rows rows, rank-major
+    double *frame = nullptr;      // root: height rows in frame order
+    hipEvent_t rendered = nullptr, consumed = nullptr;
+    bool used = false;
+};
+
+} // namespace
+
+struct trt_dist
+{
+    int device = 0, rank = 0, world = 1, root = 0;
+    int width = 0, height = 0, tile_rows = 8;
+    trt_rowset rows{};
+    int local_rows = 0, max_rows = 0;
+    std::vector<int> rows_of_rank; // rows owned by every rank
+    std::vector<Slot> slots;
+    hipStream_t comm_stream = nullptr;
+    ncclComm_t comm = nullptr;
+    int *d_source_row = nullptr; // root: frame row -> row of the gather buffer
+    bool through_comm = false;   // world > 1, or world == 1 with an id given: the gather path is taken (with no peers to receive from)
+    long calls = 0;
+};
+
+extern "C" const char *trt_dist_last_error(void) { return g_dist_error; }
+
+extern "C" int trt_dist_unique_id(void *id_out)
+{
+    if (!id_out)
+        return dist_fail(TRT_ERR_ARGUMENT, "id_out is NULL");
+    Rccl *R = rccl();
+    if (!R)
+        return dist_fail(TRT_ERR_NOT_INITIALISED, "%s", rccl_why());
+    static_assert(sizeof(ncclUniqueId) == TRT_DIST_ID_BYTES, "trt_hip.h states the size of the id");
+    ncclUniqueId id;
+    DIST_NCCL(R, R->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return TRT_OK;
+}
+
+extern "C" int trt_dist_destroy(trt_dist *d)
+{
+    if (!d)
+        return TRT_OK;
+    (void)hipSetDevice(d->device);
+    for (Slot &s : d->slots)
+        if (s.ctx)
+            (void)trt_synchronize(s.ctx);
+    if (d->comm_stream)
+        (void)hipStreamSynchronize(d->comm_stream);
+    if (d->comm)
+        if (Rccl *R = rccl())
+            (void)R->CommDestroy(d->comm);
+    for (Slot &s : d->slots)
+    {
+        if (s.rendered)
+            (void)hipEventDestroy(s.rendered);
+        if (s.consumed)
+            (void)hipEventDestroy(s.consumed);
+        if (s.gathered)
+            (void)hipFree(s.gathered);
+        else if (s.shard)
+            (void)hipFree(s.shard);
+        if (s.frame)
+            (void)hipFree(s.frame);
+        if (s.ctx)
+            (void)trt_destroy(s.ctx);
+    }
+    if (d->d_source_row)
+        (void)hipFree(d->d_source_row);
+    if (d->comm_stream)
+        (void)hipStreamDestroy(d->comm_stream);
+    delete d;
+    return TRT_OK;
+}
+
+extern "C" int trt_dist_create(int device, const Scene *scene, const void *id, int rank, int world, int width, int height, int tile_rows,
+                               int frames_in_flight, int reserved_cus, trt_dist **out)
+{
+    if (!out)
+        return dist_fail(TRT_ERR_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (!scene || world < 1 || rank < 0 || rank >= world || width < 1 || height < 1 || tile_rows < 1 || frames_in_flight < 1 ||
+        frames_in_flight > 8 || reserved_cus < 0 || (world > 1 && !id))
+        return dist_fail(TRT_ERR_ARGUMENT, "bad argument (rank %d of %d, %d x %d, tiles of %d rows, %d frames in flight)", rank, world, width,
+                         height, tile_rows, frames_in_flight);
+    trt_dist *d = new trt_dist();
+    d->device = device, d->rank = rank, d->world = world;
+    d->through_comm = world > 1 || id != nullptr;
+    d->width = width, d->height = height, d->tile_rows = tile_rows;
+    d->rows = trt_rowset{width, height, tile_rows, rank, world};
+    d->local_rows = trt_rowset_rows(&d->rows);
+    for (int r = 0; r < world; r++)
+    {
+        const trt_rowset rs = {width, height, tile_rows, r, world};
+        d->rows_of_rank.push_back(trt_rowset_rows(&rs));
+        d->max_rows = std::max(d->max_rows, d->rows_of_rank.back());
+    }
+    auto bail = [&](int rc) {
+        char keep[sizeof g_dist_error];
+        memcpy(keep, g_dist_error, sizeof keep);
+        (void)trt_dist_destroy(d);
+        memcpy(g_dist_error, keep, sizeof keep);
+        return rc;
+    };
+#define DIST_TRY(expr)                \
+    do                                \
+    {                                 \
+        const int rc_ = (expr);       \
+        if (rc_ != TRT_OK)            \
+            return bail(rc_);         \
+    } while (0)
+#define DIST_TRT(expr)                                                                     \
+    do                                                                                     \
+    {                                                                                      \
+        const int rc_ = (expr);                                                            \
+        if (rc_ != TRT_OK)                                                                 \
+            return bail(dist_fail(rc_, "%s: %s", #expr, trt_last_error()));                \
+    } while (0)
+#define DIST_HIP_B(expr)                                                                                         \
+    do                                                                                                           \
+    {                                                                                                            \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess)                                                                                    \
+            return bail(dist_fail(TRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__)); \
+    } while (0)
+
+    DIST_HIP_B(hipSetDevice(device));
+    const size_t row_doubles = (size_t)width * 3;
+    d->slots.resize((size_t)frames_in_flight);
+    for (Slot &s : d->slots)
+    {
+        DIST_TRT(trt_create(device, &s.ctx));
+        DIST_TRT(trt_set_scene(s.ctx, scene));
+        if (reserved_cus > 0)
+            DIST_TRT(trt_reserve_cus(s.ctx, reserved_cus));
+        void *stream = nullptr;
+        DIST_TRT(trt_get_stream(s.ctx, &stream));
+        s.stream = (hipStream_t)stream;
+        if (rank == d->root && d->through_comm)
+        { // the root renders straight into its part of the gather buffer
+            DIST_HIP_B(hipMalloc((void **)&s.gathered, (size_t)world * d->max_rows * row_doubles * sizeof(double)));
+            s.shard = s.gathered + (size_t)rank * d->max_rows * row_doubles;
+            DIST_HIP_B(hipMalloc((void **)&s.frame, (size_t)height * row_doubles * sizeof(double)));
+        }
+        else
+            DIST_HIP_B(hipMalloc((void **)&s.shard, (size_t)std::max(d->max_rows, 1) * row_doubles * sizeof(double)));
+        DIST_HIP_B(hipEventCreateWithFlags(&s.rendered, hipEventDisableTiming));
+        DIST_HIP_B(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
+    }
+    if (d->through_comm)
+    {
+        Rccl *R = rccl();
+        if (!R)
+            return bail(dist_fail(TRT_ERR_NOT_INITIALISED, "%s", rccl_why()));
+        DIST_HIP_B(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof uid);
+        const ncclResult_t r = R->CommInitRank(&d->comm, world, uid, rank);
+        if (r != ncclSuccess)
+            return bail(dist_fail(TRT_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, R->GetErrorString(r)));
+        if (rank == d->root)
+        { // frame row -> row of the rank-major gather buffer (the tile map of trt_rowset_frame_row)
+            std::vector<int> source((size_t)height, -1);
+            for (int r2 = 0; r2 < world; r2++)
+            {
+                const trt_rowset rs = {width, height, tile_rows, r2, world};
+                for (int i = 0; i < d->rows_of_rank[(size_t)r2]; i++)
+                    source[(size_t)trt_rowset_frame_row(&rs, i)] = r2 * d->max_rows + i;
+            }
+            for (int v : source)
+                if (v < 0)
+                    return bail(dist_fail(TRT_ERR_ARGUMENT, "the row tiles do not cover the frame"));
+            DIST_HIP_B(hipMalloc((void **)&d->d_source_row, source.size() * sizeof(int)));
+            DIST_HIP_B(hipMemcpy(d->d_source_row, source.data(), source.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    *out = d;
+    return TRT_OK;
+#undef DIST_TRY
+#undef DIST_TRT
+#undef DIST_HIP_B
+}
+
+extern "C" int trt_dist_set_scene(trt_dist *d, const Scene *scene)
+{
+    if (!d || !scene)
+        return dist_fail(TRT_ERR_ARGUMENT, "NULL argument");
+    for (Slot &s : d->slots)
+    {
+        const int rc = trt_set_scene(s.ctx, scene); // synchronises the slot's stream first
+        if (rc)
+            return dist_fail(rc, "trt_set_scene: %s", trt_last_error());
+    }
+    return TRT_OK;
+}
+
+extern "C" int trt_dist_render(trt_dist *d, const Camera *camera, int bounce_limit, int rays_per_pixel, void **d_frame)
+{
+    if (!d || !camera)
+        return dist_fail(TRT_ERR_ARGUMENT, "NULL argument");
+    DIST_HIP(hipSetDevice(d->device));
+    Slot &s = d->slots[(size_t)(d->calls % (long)d->slots.size())];
+    d->calls++;
+    const size_t row_doubles = (size_t)d->width * 3;
+    if (s.used && d->through_comm)
+        DIST_HIP(hipStreamWaitEvent(s.stream, s.consumed, 0)); // the slot's previous shard has left (or been assembled)
+    s.used = true;
+    if (d->local_rows > 0)
+    {
+        const int rc = trt_render_device(s.ctx, camera, &d->rows, bounce_limit, rays_per_pixel, s.shard,
+                                         (size_t)std::max(d->max_rows, 1) * row_doubles * sizeof(double));
+        if (rc)
+            return dist_fail(rc, "trt_render_device: %s", trt_last_error());
+    }
+    if (!d->through_comm)
+    {
+        if (d_frame)
+            *d_frame = s.shard; // a single renderer's rows are the frame, in order; valid in stream order of the slot's stream
+        return TRT_OK;
+    }
+    Rccl *R = rccl();
+    DIST_HIP(hipEventRecord(s.rendered, s.stream));
+    DIST_HIP(hipStreamWaitEvent(d->comm_stream, s.rendered, 0));
+    DIST_NCCL(R, R->GroupStart());
+    if (d->rank == d->root)
+    {
+        for (int r = 0; r < d->world; r++)
+            if (r != d->root && d->rows_of_rank[(size_t)r] > 0)
+                DIST_NCCL(R, R->Recv(s.gathered + (size_t)r * d->max_rows * row_doubles, (size_t)d->rows_of_rank[(size_t)r] * row_doubles, ncclDouble, r,
+                                     d->comm, d->comm_stream));
+    }
+    else if (d->local_rows > 0)
+        DIST_NCCL(R, R->Send(s.shard, (size_t)d->local_rows * row_doubles, ncclDouble, d->root, d->comm, d->comm_stream));
+    DIST_NCCL(R, R->GroupEnd());
+    if (d->rank == d->root)
+    {
+        const long total = (long)d->height * (long)row_doubles;
+        hipLaunchKernelGGL(assemble_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->comm_stream, (const double *)s.gathered,
+                           (const int *)d->d_source_row, s.frame, (long)row_doubles, total);
+        DIST_HIP(hipGetLastError());
+    }
+    DIST_HIP(hipEventRecord(s.consumed, d->comm_stream));
+    if (d_frame)
+        *d_frame = d->rank == d->root ? s.frame : nullptr;
+    return TRT_OK;
+}
+
+extern "C" int trt_dist_synchronize(trt_dist *d)
+{
+    if (!d)
+        return dist_fail(TRT_ERR_ARGUMENT, "d is NULL");
+    DIST_HIP(hipSetDevice(d->device));
+    for (Slot &s : d->slots)
+        DIST_HIP(hipStreamSynchronize(s.stream));
+    if (d->comm_stream)
+        DIST_HIP(hipStreamSynchronize(d->comm_stream));
+    return TRT_OK;
+}
+
+extern "C" int trt_dist_info(const trt_dist *d, int *rank, int *world, int *local_rows, int *max_rows, int *frames_in_flight)
+{
+    if (!d)
+        return dist_fail(TRT_ERR_ARGUMENT, "d is NULL");
+    if (rank)
+        *rank = d->rank;
+    if (world)
+        *world = d->world;
+    if (local_rows)
+        *local_rows = d->local_rows;
+    if (max_rows)
+        *max_rows = d->max_rows;
+    if (frames_in_flight)
+        *frames_in_flight = (int)d->slots.size();
+    return TRT_OK;
+}
+
+extern "C" int trt_dist_fetch(trt_dist *d, const void *d_frame, Vector *pixels)
+{
+    if (!d || !d_frame || !pixels)
+        return dist_fail(TRT_ERR_ARGUMENT, "NULL argument");
+    const int rc = trt_dist_synchronize(d);
+    if (rc)
+        return rc;
+    DIST_HIP(hipMemcpy(pixels, d_frame, (size_t)d->width * d->height * sizeof(Vector), hipMemcpyDeviceToHost));
+    return TRT_OK;
+}
+
+extern "C" trt_context *trt_dist_context(trt_dist *d, int slot)
+{
+    if (!d || slot < 0 || slot >= (int)d->slots.size())
+        return nullptr;
+    return d->slots[(size_t)slot].ctx;
+}

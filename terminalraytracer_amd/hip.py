@@ -79,6 +79,16 @@ SYMBOLS = {
     "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
     "trt_probe_rays": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
     "trt_probe_rays_production": (_I, [_VP, C.POINTER(L.Camera), _VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
+    "trt_dist_unique_id": (_I, [_VP]),
+    "trt_dist_create": (_I, [_I, C.POINTER(L.Scene), _VP, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_VP)]),
+    "trt_dist_set_scene": (_I, [_VP, C.POINTER(L.Scene)]),
+    "trt_dist_render": (_I, [_VP, C.POINTER(L.Camera), _I, _I, C.POINTER(_VP)]),
+    "trt_dist_synchronize": (_I, [_VP]),
+    "trt_dist_fetch": (_I, [_VP, _VP, _VP]),
+    "trt_dist_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
+    "trt_dist_context": (_VP, [_VP, _I]),
+    "trt_dist_destroy": (_I, [_VP]),
+    "trt_dist_last_error": (C.c_char_p, []),
     "trt_last_error": (C.c_char_p, []),
     "trt_version": (C.c_char_p, []),
 }
@@ -121,15 +131,19 @@ class Context:
 
     PRODUCTION, REFERENCE_ORDER = 0, 1
 
-    def __init__(self, device=0):
-        self._h = _VP()
-        _check(lib().trt_create(device, C.byref(self._h)))
+    def __init__(self, device=0, _borrowed=None):
+        self._owned = _borrowed is None
+        if self._owned:
+            self._h = _VP()
+            _check(lib().trt_create(device, C.byref(self._h)))
+        else:
+            self._h = _VP(_borrowed)  # a context owned by someone else (trt_dist_context)
         self.device = device
 
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             lib().trt_destroy(self._h)
-            self._h = _VP()
+        self._h = _VP()
 
     def __enter__(self):
         return self
@@ -304,3 +318,70 @@ def project_scene(scene_data, width, height):
     screen, pixels = new_screen(width, height)
     lib().project_scene(C.byref(scene), C.byref(screen))
     return pixels
+
+
+def _dist_check(code):
+    if code != TRT_OK:
+        raise TrtError(code, lib().trt_dist_last_error().decode())
+
+
+def dist_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0; trt_dist_unique_id)"""
+    buf = C.create_string_buffer(128)
+    _dist_check(lib().trt_dist_unique_id(buf))
+    return buf.raw
+
+
+class Dist:
+    """trt_dist: this rank's part of one frame sharded over the GPUs of a node (include/trt_hip.h, section 3).
+    Row tiles, the RCCL communicator, the gather and the frame pipeline all live in the library."""
+
+    def __init__(self, device, scene_data, unique_id, rank, world, width, height, tile_rows=8, frames_in_flight=2, reserved_cus=0):
+        self._h = _VP()
+        self._scene = scene_data.as_scene()
+        idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        _dist_check(lib().trt_dist_create(device, C.byref(self._scene), idbuf, rank, world, width, height, tile_rows, frames_in_flight,
+                                          reserved_cus, C.byref(self._h)))
+        self.device, self.rank, self.world, self.width, self.height = device, rank, world, width, height
+        self.frames_in_flight = frames_in_flight
+        v = [_I() for _ in range(5)]
+        _dist_check(lib().trt_dist_info(self._h, *[C.byref(x) for x in v]))
+        self.local_rows, self.max_rows = v[2].value, v[3].value
+
+    def context(self, slot=0):
+        h = lib().trt_dist_context(self._h, slot)
+        if not h:
+            raise IndexError(slot)
+        return Context(self.device, _borrowed=h)
+
+    def render(self, camera_array, bounce_limit, rays_per_pixel):
+        """enqueue one frame; returns the device address of the assembled frame on rank 0 (None elsewhere)"""
+        cam = camera_struct(camera_array)
+        out = _VP()
+        _dist_check(lib().trt_dist_render(self._h, C.byref(cam), bounce_limit, rays_per_pixel, C.byref(out)))
+        return out.value
+
+    def synchronize(self):
+        _dist_check(lib().trt_dist_synchronize(self._h))
+
+    def fetch(self, device_frame):
+        out = np.zeros((self.height, self.width, 3), dtype=np.float64)
+        _dist_check(lib().trt_dist_fetch(self._h, _VP(device_frame), out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().trt_dist_destroy(self._h)
+            self._h = _VP()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -274,6 +274,53 @@ def test_gpu_frame_through_the_host_emitter_matches_reference_bytes(ctx):
     assert em.bytes() == want
 
 
+@pytest.mark.parametrize("through_rccl", [False, True], ids=["plain", "one_rank_rccl_communicator"])
+def test_c_abi_dist_renderer_world_of_one(ctx, through_rccl):
+    """trt_dist_* (include/trt_hip.h section 3) with one rank: the row tiles, the frame pipeline (three frames in flight,
+    compute units reserved) and -- with an id -- a one-rank RCCL communicator with the whole gather path (group, assembly
+    kernel) inside the library.  Every frame of a short orbit must equal the oracle's, in order."""
+    case = next(c for c in SMALL if c["name"] == "synth64_128x72_b8")
+    scene = T.golden_scene(case)
+    uid = hip.dist_unique_id() if through_rccl else None
+    with hip.Dist(0, scene, uid, 0, 1, 128, 72, tile_rows=8, frames_in_flight=3, reserved_cus=8) as d:
+        assert (d.local_rows, d.max_rows) == (72, 72)
+        frames = [d.render(scene.camera, 8, 10) for _ in range(7)]  # every slot reused at least twice
+        assert T.fnv(d.fetch(frames[-1])) == case["fb_fnv"]
+        for t in (0.0, 2.5, 33.3):
+            cam = T.bench_camera(128, 72, t)
+            got = d.fetch(d.render(cam, 8, 10))
+            want, _ = T.oracle_render(scene.with_camera(cam), 128, 72, 8, 10)
+            assert np.array_equal(bits(got), bits(want)), t
+        assert d.context(0).kernel_info()["compute_units"] >= 8
+        with pytest.raises(IndexError):
+            d.context(3)
+    with pytest.raises(hip.TrtError):
+        hip.Dist(0, scene, None, 0, 2, 128, 72)  # more than one rank needs the communicator's id
+
+
+def test_c_host_drives_the_dist_renderer(tmp_path):
+    """examples/trt_dist_demo: a C host, one process per GPU, the communicator id carried through a file -- here one rank, so
+    communicator, group and assembly all run on the one GPU.  Its last frame must be the frame the single-GPU C demo's
+    project_scene produces for the same camera (frame 2 of the orbit at 60 frames per second of scene time)."""
+    import os
+    import subprocess
+    exe = os.path.join(T.ROOT, "examples", "trt_dist_demo")
+    if not os.path.exists(exe):
+        pytest.skip("examples/trt_dist_demo not built")
+    sky = tmp_path / "colors"
+    sky.mkdir()
+    for f in T.FACES:
+        (sky / (f + ".ppm")).write_bytes(T.golden_ppm_raw("colors", f))
+    out = subprocess.run([exe, str(sky), "0", "1", str(tmp_path / "id"), "3", "160", "48"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert "3 frames 160x48 on 1 GPU(s)" in out.stdout
+    from terminalraytracer_amd import host
+    cam = host.orbit_camera(2 / 60.0, 160, 48)
+    scene = S.demo_scene(T.sky("colors"), cam)
+    want, _ = T.oracle_render(scene, 160, 48, 10, 10)
+    assert T.fnv(want) in out.stdout, out.stdout
+
+
 def test_sharded_renderer_world_of_one(ctx):
     from terminalraytracer_amd.distributed import HipShardRenderer
     case = next(c for c in SMALL if c["name"] == "synth64_128x72_b8")
