@@ -77,10 +77,10 @@ def animation_cameras(width, height, frames):
     return [c for c in cams]
 
 
-def build_scene(workload="c3"):
+def build_scene(workload="c3", sky_dim=SKY_DIM):
     from terminalraytracer_amd import scenes as S
     w = WORKLOADS[workload]
-    return S.synth_scene(w["spheres"], S.synth_sky(SKY_DIM), stored_camera(w["width"], w["height"], 1.0), seed=SEED)
+    return S.synth_scene(w["spheres"], S.synth_sky(sky_dim), stored_camera(w["width"], w["height"], 1.0), seed=SEED)
 
 
 # names kept for the tools/ scripts
@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
     ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = 2)")
     ap.add_argument("--tile-rows", type=int, default=8, help="rows per interleaved tile of the row sharding")
+    ap.add_argument("--sky-dim", type=int, default=SKY_DIM, help="cubemap face size (the frame is only verified at the default, 256)")
     ap.add_argument("--reserve-cus", type=int, default=0, help="compute units kept free of render workgroups so that the gather's kernels can "
                                                               "run beside them (a guess until an 8-GPU run has been made: default 0)")
     args = ap.parse_args()
@@ -190,7 +191,9 @@ def main():
             dist.init_process_group(args.backend)
     torch.cuda.set_device(local)
 
-    scene = build_scene(workload)
+    scene = build_scene(workload, args.sky_dim)
+    if args.sky_dim != SKY_DIM:
+        args.no_verify = True  # the reference's hashes are for the 256^2 cubemap
     cameras = animation_cameras(width, height, args.animation) if args.animation > 0 else [scene.camera]
     camera_of = lambda step: cameras[step % len(cameras)]  # noqa: E731
     rehearsal = world > 1 and args.backend != "nccl"
@@ -303,7 +306,7 @@ def main():
         ms_step = seconds / args.steps * 1e3
         rows = local_rows
         nd, npt = scene.dir_lights.shape[0], scene.point_lights.shape[0]
-        alg = algorithmic_bytes(width, rows, wl["spheres"], SKY_DIM, nd, npt)
+        alg = algorithmic_bytes(width, rows, wl["spheres"], args.sky_dim, nd, npt)
         achieved = alg / (render_ms_avg * 1e-3) / 1e9
         path_mean = float(np.mean(path_cam))
         prof = committed_profile() if (world == 1 and workload == "c3") else None
@@ -315,7 +318,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl["text"], "sharding": f"{world} x interleaved {args.tile_rows}-row tiles, 1 gather/frame",
+            "config": {"workload": wl["text"] if args.sky_dim == SKY_DIM else wl["text"].replace("256^2", f"{args.sky_dim}^2"), "sharding": f"{world} x interleaved {args.tile_rows}-row tiles, 1 gather/frame",
                        "multi_gpu_path": "PyTorch-level rehearsal (gloo)" if rehearsal else "C-ABI trt_dist_* (RCCL send/recv gather inside the library)",
                        "kernel": {0: "persistent waves, synchronous rounds", 1: "reference-order"}[args.kernel],
                        "frames_in_flight": args.depth, "reserved_cus": args.reserve_cus},

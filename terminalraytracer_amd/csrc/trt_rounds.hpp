@@ -219,6 +219,12 @@ TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool val
 // indices ascending, up to seven inline, longer lists in `pool`).  Otherwise the wave sweeps the FP32 culling table
 // (trt_filter.h) -- `fixed` != nullptr: all rays share the direction that culling table was built for -- and each lane
 // pops its candidate bits.
+// TRT_LIST_PREFILTER: lists longer than this many entries in some lane of the wave are first thinned by the FP32 filter
+// (0 = never).
+#ifndef TRT_LIST_PREFILTER
+#define TRT_LIST_PREFILTER 12
+#endif
+
 template <bool ANY_HIT>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
                   const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool
@@ -246,7 +252,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     if (use_list)
     {
         const unsigned ctl = (unsigned)(cell >> 56);
-        const bool pooled = (ctl & TRT_LIST_POOLED) != 0;
+        bool pooled = (ctl & TRT_LIST_POOLED) != 0;
         int count = active ? (pooled ? (int)((cell >> 32) & 0xffffu) : (int)ctl) : 0;
         const unsigned at = (unsigned)cell; // pooled: offset of the list's words
         unsigned long long cur = cell;
@@ -255,6 +261,51 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         TRT_TRACE_STAMP(0); // table load
+#if TRT_LIST_PREFILTER
+        // Long lists (dense scenes): the FP32 filter of trt_filter.h first goes over the list -- 9 FP32 operations per entry
+        // instead of ~19 FP64 -- and only the entries it cannot reject go to the exact test.  Like the sweep it never decides
+        // a hit.  Up to eight survivors fit one 64-bit word; if some lane has more, the wave tests its lists directly.
+        if (__any(count > TRT_LIST_PREFILTER))
+        {
+            trt_ray_filter flt;
+            trt_filter_setup(&flt, o.x, o.y, o.z, d.x, d.y, d.z, a, cull.c0x, cull.c0y, cull.c0z, cull.cn, cull.rm);
+            unsigned long long kept = 0, word = cell;
+            int nk = 0;
+            bool over = false;
+            for (int j = 0; __any(j < count); j++)
+            {
+                const bool valid = j < count;
+                if (__any(valid && pooled && (j & 7) == 0))
+                    if (valid && pooled && (j & 7) == 0)
+                        word = pool[at + ((unsigned)j >> 3)];
+                const unsigned i = valid ? (unsigned)word & 0xffu : 0u;
+                word >>= 8;
+                unsigned sign;
+                if (ANY_HIT && fixed)
+                {
+                    const float4 e = fixed[i];
+                    sign = trt_filter_sign_fixed_dir(&flt, e.x, e.y, e.z, e.w);
+                }
+                else
+                {
+                    const float4 e = L.cull[i];
+                    sign = trt_filter_sign(&flt, e.x, e.y, e.z, e.w);
+                }
+                if (valid && (!flt.ok || !(sign >> 31)))
+                {
+                    over = over || nk == 8;
+                    kept |= nk < 8 ? (unsigned long long)i << (8 * nk) : 0ull;
+                    nk++;
+                }
+            }
+            if (!__any(over))
+            { // the survivors are the list now: ascending as before
+                cur = kept;
+                count = nk;
+                pooled = false;
+            }
+        }
+#endif
         TRT_TRACE_STAMP(1);
         while (__any(k < count))
         {
