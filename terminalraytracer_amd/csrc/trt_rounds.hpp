@@ -225,6 +225,7 @@ TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool val
 #define TRT_LIST_PREFILTER 12
 #endif
 
+
 template <bool ANY_HIT>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
                   const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool
