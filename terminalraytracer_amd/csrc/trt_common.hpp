@@ -9,7 +9,11 @@
 namespace trt
 {
 
-constexpr int kPersistentBlock = 256;
+// threads per workgroup of the persistent kernels: 256 = 4 waves share one LDS image, 4 workgroups per CU
+#ifndef TRT_BLOCK
+#define TRT_BLOCK 256
+#endif
+constexpr int kPersistentBlock = TRT_BLOCK;
 
 // TRT_STAMP=1: diagnostic build with s_memtime stamps between the stages of the main loop; per-stage wave-cycle
 // sums go to counters[4..] (read SHARES from it, never its run time: the stamps fence the schedule).

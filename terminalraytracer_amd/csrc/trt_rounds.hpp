@@ -619,7 +619,11 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
 // (<= 128) -- with a better schedule than when it is forced under 128 (measured 3.02 vs 3.15 ms).  The build records the
 // compiler's resource report in build/resource_usage.txt and `make lib` warns if this kernel ever needs more than 128.
 #ifndef TRT_ROUNDS_WAVES
+#if TRT_BLOCK > 768
+#define TRT_ROUNDS_WAVES 4 // a 1024-thread workgroup is 4 waves per SIMD by itself
+#else
 #define TRT_ROUNDS_WAVES 3
+#endif
 #endif
 
 template <bool COUNT>
