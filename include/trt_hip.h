@@ -154,6 +154,9 @@ int trt_set_light_grids(trt_context *ctx, int directional_cells, int point_cells
  * 0, 0 turns them off (every path ray sweeps); frames are bit-identical either way.  Defaults 64 and 32; environment
  * TRT_PATHGRID="e,s" overrides the defaults.  Scenes with more than 256 spheres render without any candidate table. */
 int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_cells);
+/* Scenes with fewer than `min_spheres` spheres keep the sweep for their path rays: below about a dozen spheres 9 VALU per
+ * sphere are cheaper than a look-up with its membership test (default 12; 0 = tables for every scene). */
+int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres);
 
 /* Copy the path rays' tables to the host (tests: the device-built lists must equal the host reference builder's): list
  * cells (2*6*eye_cells^2, then 2N*6*sphere_cells^2) and the pool of long lists, as built for `camera`'s eye.

@@ -32,6 +32,11 @@
 #ifndef TRT_PATHGRID_SPHERE
 #define TRT_PATHGRID_SPHERE 32
 #endif
+// below this many spheres the wave-uniform sweep (9 VALU per sphere) is cheaper than a table look-up with its membership
+// test: measured 1.097 against 1.122 ms at 8 spheres (BASELINE config 2), 0.159 against 0.169 ms at 6 (the demo scene)
+#ifndef TRT_PATHGRID_MIN_SPHERES
+#define TRT_PATHGRID_MIN_SPHERES 12
+#endif
 
 #include "trt_common.hpp"
 #include "trt_rounds.hpp"
@@ -127,7 +132,8 @@ struct trt_context
     DeviceBuffer<trt_rayfamily> d_families;    // the 2N families of the spheres, for the marking kernel
     DeviceBuffer<double> d_sphere_fam;         // per sphere {mirror centre, r_chk}: what the render kernel keeps in LDS
     int path_g_eye = TRT_PATHGRID_EYE, path_g_sph = TRT_PATHGRID_SPHERE; // 0 = no path tables (every path ray sweeps)
-    int path_built_for[2] = {-1, -1};
+    int path_min_spheres = TRT_PATHGRID_MIN_SPHERES;                      // scenes with fewer spheres sweep
+    int path_built_for[3] = {-1, -1, -1};
     size_t pool_scene_words = 0, pool_eye_words = 0; // capacities of the two parts of d_pool
     trt_cull_scene cull_scene{};                      // of the spheres the tables were built from
     double eye_built[3] = {0.0, 0.0, 0.0}, ground_built[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -387,10 +393,11 @@ int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const double *
     ctx->eye_tables_valid = false;
     ctx->path_built_for[0] = ctx->path_g_eye;
     ctx->path_built_for[1] = ctx->path_g_sph;
+    ctx->path_built_for[2] = ctx->path_min_spheres;
     ctx->cull_scene = cs;
     memcpy(ctx->ground_built, ground, sizeof ctx->ground_built);
     const int ge = ctx->path_g_eye, gs = ctx->path_g_sph;
-    if (ge < 2 || gs < 2 || n > TRT_LIST_MAX_SPHERES)
+    if (ge < 2 || gs < 2 || n > TRT_LIST_MAX_SPHERES || n < ctx->path_min_spheres)
         return TRT_OK; // path_enabled = 0: every path ray sweeps
     const size_t eye_cells = 6 * (size_t)ge * ge, sph_cells = 6 * (size_t)gs * gs;
     HIP_TRY(ctx->d_path_lists.reserve(2 * eye_cells + 2 * (size_t)n * sph_cells));
@@ -508,6 +515,7 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
                       (!np || !memcmp(ctx->h_point.data(), hp, (size_t)np * sizeof(PointLight))) &&
                       ctx->grids_built_for[0] == ctx->dirgrid_cells && ctx->grids_built_for[1] == ctx->pointgrid_cells &&
                       ctx->path_built_for[0] == ctx->path_g_eye && ctx->path_built_for[1] == ctx->path_g_sph &&
+                      ctx->path_built_for[2] == ctx->path_min_spheres &&
                       !memcmp(ctx->ground_built, &scene->ground, sizeof ctx->ground_built);
     if (!same)
     {
@@ -862,6 +870,22 @@ extern "C" int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_ce
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still read the old tables
     ctx->path_g_eye = eye_cells;
     ctx->path_g_sph = sphere_cells;
+    if (!ctx->have_scene)
+        return TRT_OK;
+    const int n = (int)(ctx->h_spheres.size() / 9);
+    std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
+    trt_cull_scene cs;
+    trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
+    return build_tables(ctx, cs, ctx->scene.ground);
+}
+
+extern "C" int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres)
+{
+    if (!ctx || min_spheres < 0)
+        return fail(TRT_ERR_ARGUMENT, "min_spheres %d", min_spheres);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->path_min_spheres = min_spheres;
     if (!ctx->have_scene)
         return TRT_OK;
     const int n = (int)(ctx->h_spheres.size() / 9);

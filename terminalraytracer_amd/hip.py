@@ -69,6 +69,7 @@ SYMBOLS = {
     "trt_set_kernel": (_I, [_VP, _I]),
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
     "trt_set_path_grids": (_I, [_VP, _I, _I]),
+    "trt_set_path_grids_min_spheres": (_I, [_VP, _I]),
     "trt_read_path_tables": (C.c_long, [_VP, C.POINTER(L.Camera), _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_long)]),
     "trt_read_sweep_fallbacks": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
     "trt_reserve_cus": (_I, [_VP, _I]),
@@ -184,6 +185,10 @@ class Context:
     def set_path_grids(self, eye_cells, sphere_cells):
         """cells per cube-map face side of the path rays' family tables; 0, 0 = off (trt_set_path_grids)"""
         _check(lib().trt_set_path_grids(self._h, eye_cells, sphere_cells))
+
+    def set_path_grids_min_spheres(self, min_spheres):
+        """scenes with fewer spheres keep the sweep for their path rays (trt_set_path_grids_min_spheres)"""
+        _check(lib().trt_set_path_grids_min_spheres(self._h, min_spheres))
 
     def read_path_tables(self, camera_array):
         """(info dict, list cells uint64[], pool uint64[]) of the path rays' tables as built for this camera's eye"""
