@@ -263,24 +263,25 @@ __global__ void build_pointgrid_kernel(const trt_pointgrid_cone *cones, int n, i
 
 // Mask words of a table -> list cells (trt_raygrid.h).  Lists longer than seven entries take words from the pool; when
 // the pool's part is exhausted the cell says TRT_LIST_NONE and its rays sweep.
-__device__ unsigned long long pack_cell(const unsigned long long *mask, int words, unsigned long long *pool, unsigned *pool_used, unsigned pool_limit)
+__device__ unsigned long long pack_cell(const unsigned long long *mask, int words, unsigned long long *pool, unsigned *pool_used, unsigned pool_limit,
+                                        int bits)
 {
     const int count = trt_list_count(mask, words);
-    if (count <= 7)
-        return trt_list_pack(mask, words, count, nullptr, 0u);
-    const unsigned need = (unsigned)(count + 7) / 8u;
+    const unsigned need = trt_list_pool_words(count, bits);
+    if (need == 0)
+        return trt_list_pack(mask, words, count, nullptr, 0u, bits);
     const unsigned at = atomicAdd(pool_used, need);
-    if (at + need > pool_limit || at + need < at)
+    if (count > 0xffff || at + need > pool_limit || at + need < at)
         return (unsigned long long)TRT_LIST_NONE << 56;
-    return trt_list_pack(mask, words, count, pool, at);
+    return trt_list_pack(mask, words, count, pool, at, bits);
 }
 
 __global__ void pack_lists_kernel(const unsigned long long *masks, long cells, int words, unsigned long long *lists, unsigned long long *pool,
-                                  unsigned *pool_used, unsigned pool_limit)
+                                  unsigned *pool_used, unsigned pool_limit, int bits)
 {
     const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell < cells)
-        lists[cell] = pack_cell(masks + cell * words, words, pool, pool_used, pool_limit);
+        lists[cell] = pack_cell(masks + cell * words, words, pool, pool_used, pool_limit, bits);
 }
 
 // Direction tables of path-ray families (trt_raygrid.h): blockIdx.y = family, one thread per cell.  Every block first forms
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void build_family_lists_kernel(const double *s
     for (int i = 0; i < n; i++)
         if (trt_pointgrid_reaches(&cones[i], face, c, j, g))
             m[i >> 6] |= 0x8000000000000000ull >> (i & 63);
-    lists[(size_t)blockIdx.y * cells + cell] = pack_cell(m, (n + 63) / 64 > 0 ? (n + 63) / 64 : 1, pool, pool_used, pool_limit);
+    lists[(size_t)blockIdx.y * cells + cell] = pack_cell(m, (n + 63) / 64 > 0 ? (n + 63) / 64 : 1, pool, pool_used, pool_limit, 8);
 }
 
 // Light-space candidate masks of every light (trt_lightgrid.h), from the context's host copy of the primitives: the
@@ -318,8 +319,10 @@ int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
     g.enabled = 0;
     ctx->grids_built_for[0] = gd;
     ctx->grids_built_for[1] = gp;
-    if (gd < 8 || gp < 2 || nd + np == 0 || n > TRT_LIST_MAX_SPHERES)
+    if (gd < 8 || gp < 2 || nd + np == 0 || n > TRT_LIST_MAX_SPHERES_WIDE)
         return TRT_OK; // enabled = 0: the kernel sweeps
+    const int bits = n > TRT_LIST_MAX_SPHERES ? 16 : 8; // entry width of the list cells
+    g.list_bits = bits;
     const size_t words = (size_t)std::max((n + 63) / 64, 1), slots = (size_t)std::max(n, 1);
     const size_t dir_stride = (size_t)gd * gd * words, point_stride = 6 * (size_t)gp * gp * words;
     std::vector<trt_dirgrid> dg(nd);
@@ -366,10 +369,10 @@ int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
     HIP_TRY(ctx->d_point_lists.reserve(point_cells * np));
     if (nd)
         hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((dir_cells * nd + block - 1) / block)), dim3(block), 0, ctx->stream, ctx->d_dir_masks.ptr,
-                           (long)(dir_cells * nd), (int)words, ctx->d_dir_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words);
+                           (long)(dir_cells * nd), (int)words, ctx->d_dir_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words, bits);
     if (np)
         hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((point_cells * np + block - 1) / block)), dim3(block), 0, ctx->stream, ctx->d_point_masks.ptr,
-                           (long)(point_cells * np), (int)words, ctx->d_point_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words);
+                           (long)(point_cells * np), (int)words, ctx->d_point_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words, bits);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // the caller may hand the context another stream before it renders
     g.dir = ctx->d_dirgrids.ptr;
@@ -441,7 +444,10 @@ int build_tables(trt_context *ctx, const trt_cull_scene &cs, const double *groun
     ctx->pool_eye_words = std::max<size_t>(1024, 2 * 6 * ge * ge);
     if (ctx->pool_scene_words + ctx->pool_eye_words >= 0xffffffffull)
         return fail(TRT_ERR_CAPACITY, "candidate tables too large");
+    if (n > TRT_LIST_MAX_SPHERES) // no sphere families; 16-bit entries: long lists take twice the words
+        ctx->pool_scene_words = std::max<size_t>(1024, 2 * (nd * gd * gd + np * 6 * gp * gp));
     ctx->grids = trt::GridView{};
+    ctx->grids.list_bits = 8;
     HIP_TRY(ctx->d_pool.reserve(ctx->pool_scene_words + ctx->pool_eye_words));
     HIP_TRY(ctx->d_pool_used.reserve(32));
     HIP_TRY(hipMemsetAsync(ctx->d_pool_used.ptr, 0, 32 * sizeof(unsigned), ctx->stream));

@@ -39,7 +39,8 @@
  * LIST CELLS.  Every candidate table the kernel reads -- these and the light tables -- is stored as one 64-bit word per
  * cell: byte 7 = count 0..7 and bytes 0..6 the sphere indices in ascending order; or byte 7 = 0x80, bits 32..47 = count,
  * bits 0..31 = the offset of ceil(count/8) words of indices in a pool; or byte 7 = 0xFF: no list (pool exhausted), the
- * ray falls back to the sweep.  One 8-byte load whatever N is (N <= 256), and the exact stage pops bytes.
+ * ray falls back to the sweep.  One 8-byte load whatever N is, and the exact stage pops bytes.  Scenes of more than 256
+ * spheres use 16-bit entries (3 inline, 4 per pool word) for their light tables and sweep for their path rays.
  */
 #ifndef TRT_RAYGRID_H
 #define TRT_RAYGRID_H
@@ -56,8 +57,10 @@ typedef struct
 
 #define TRT_RAYFAMILY_DOUBLES 6
 
-/* maximum sphere count the list cells can index */
+/* list cells index spheres with 8 bits (scenes of up to 256 spheres: every table) or 16 bits (light tables of larger scenes;
+ * the path rays' family tables are only built up to TRT_LIST_MAX_SPHERES) */
 #define TRT_LIST_MAX_SPHERES 256
+#define TRT_LIST_MAX_SPHERES_WIDE 65535
 #define TRT_LIST_POOLED 0x80u
 #define TRT_LIST_NONE 0xFFu
 
@@ -201,9 +204,12 @@ TRT_HD int trt_list_count(const unsigned long long *mask, int words)
     return count;
 }
 
-TRT_HD unsigned long long trt_list_pack(const unsigned long long *mask, int words, int count, unsigned long long *pool, unsigned pool_offset)
+/* `bits`: 8 (scenes of up to 256 spheres) or 16 bits per entry: 7 or 3 entries inline, 8 or 4 per pool word */
+TRT_HD unsigned long long trt_list_pack(const unsigned long long *mask, int words, int count, unsigned long long *pool, unsigned pool_offset,
+                                        int bits)
 {
-    if (count <= 7)
+    const int per = 64 / bits, inline_max = 56 / bits;
+    if (count <= inline_max)
     {
         unsigned long long cell = (unsigned long long)count << 56;
         int k = 0;
@@ -214,7 +220,7 @@ TRT_HD unsigned long long trt_list_pack(const unsigned long long *mask, int word
             {
                 const int lead = __builtin_clzll(m);
                 m &= ~(0x8000000000000000ull >> lead);
-                cell |= (unsigned long long)(unsigned)(w * 64 + lead) << (8 * k++);
+                cell |= (unsigned long long)(unsigned)(w * 64 + lead) << (bits * k++);
             }
         }
         return cell;
@@ -230,17 +236,24 @@ TRT_HD unsigned long long trt_list_pack(const unsigned long long *mask, int word
         {
             const int lead = __builtin_clzll(m);
             m &= ~(0x8000000000000000ull >> lead);
-            cur |= (unsigned long long)(unsigned)(w * 64 + lead) << (8 * (k & 7));
-            if ((++k & 7) == 0)
+            cur |= (unsigned long long)(unsigned)(w * 64 + lead) << (bits * (k % per));
+            if (++k % per == 0)
             {
-                pool[pool_offset + (unsigned)(k >> 3) - 1u] = cur;
+                pool[pool_offset + (unsigned)(k / per) - 1u] = cur;
                 cur = 0;
             }
         }
     }
-    if (k & 7)
-        pool[pool_offset + (unsigned)(k >> 3)] = cur;
+    if (k % per)
+        pool[pool_offset + (unsigned)(k / per)] = cur;
     return ((unsigned long long)TRT_LIST_POOLED << 56) | ((unsigned long long)(unsigned)count << 32) | pool_offset;
+}
+
+/* pool words a list of `count` entries takes (0: it is inline) */
+TRT_HD unsigned trt_list_pool_words(int count, int bits)
+{
+    const int per = 64 / bits, inline_max = 56 / bits;
+    return count <= inline_max ? 0u : (unsigned)((count + per - 1) / per);
 }
 
 /* number of entries of a list cell, -1 for TRT_LIST_NONE */
@@ -253,11 +266,13 @@ TRT_HD int trt_list_entries(unsigned long long cell)
 }
 
 /* entry k of a list cell */
-TRT_HD int trt_list_entry(unsigned long long cell, const unsigned long long *pool, int k)
+TRT_HD int trt_list_entry(unsigned long long cell, const unsigned long long *pool, int k, int bits)
 {
+    const int per = 64 / bits;
+    const unsigned long long emask = (1ull << bits) - 1ull;
     if ((unsigned)(cell >> 56) & TRT_LIST_POOLED)
-        return (int)((pool[(unsigned)cell + (unsigned)(k >> 3)] >> (8 * (k & 7))) & 0xffu);
-    return (int)((cell >> (8 * k)) & 0xffu);
+        return (int)((pool[(unsigned)cell + (unsigned)(k / per)] >> (bits * (k % per))) & emask);
+    return (int)((cell >> (bits * k)) & emask);
 }
 
 /* ---- host reference builder (tests; the library marks the cells on the device with the same predicates) ---- */

@@ -52,6 +52,7 @@ struct GridView
     const unsigned long long *dir_lists, *point_lists;
     unsigned dir_stride, point_stride; // cells per light
     int enabled;
+    int list_bits; // bits per entry of every list cell: 8, or 16 for scenes of more than 256 spheres (light tables only)
     // direction tables of the path rays' families (trt_raygrid.h): families 0 (eye) and 1 (mirror eye) have 6*g_eye^2 cells
     // each, then 2N families (sphere i, then mirror sphere i) of 6*g_sph^2 cells
     int path_enabled;
@@ -228,7 +229,7 @@ TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool val
 
 template <bool ANY_HIT>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
-                  const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool
+                  const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool, int list_bits
 #if TRT_STAMP
                   ,
                   unsigned long long *stamp_sum = nullptr, unsigned long long *stamp_prev_p = nullptr, int stamp_base = 0
@@ -256,6 +257,8 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         bool pooled = (ctl & TRT_LIST_POOLED) != 0;
         int count = active ? (pooled ? (int)((cell >> 32) & 0xffffu) : (int)ctl) : 0;
         const unsigned at = (unsigned)cell; // pooled: offset of the list's words
+        const unsigned entry_mask = (1u << list_bits) - 1u;
+        const int per_shift = list_bits == 8 ? 3 : 2, per_mask = (1 << per_shift) - 1; // 8 or 4 entries per pool word
         unsigned long long cur = cell;
         int k = 0;
 #if TRT_STAMP
@@ -265,7 +268,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
 #if TRT_LIST_PREFILTER
         // Long lists (dense scenes): the FP32 filter of trt_filter.h first goes over the list -- 9 FP32 operations per entry
         // instead of ~19 FP64 -- and only the entries it cannot reject go to the exact test.  Like the sweep it never decides
-        // a hit.  Up to eight survivors fit one 64-bit word; if some lane has more, the wave tests its lists directly.
+        // a hit.  Up to eight survivors (four of 16 bits) fit one 64-bit word; if some lane has more, the wave tests its lists directly.
         if (__any(count > TRT_LIST_PREFILTER))
         {
             trt_ray_filter flt;
@@ -276,11 +279,11 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
             for (int j = 0; __any(j < count); j++)
             {
                 const bool valid = j < count;
-                if (__any(valid && pooled && (j & 7) == 0))
-                    if (valid && pooled && (j & 7) == 0)
-                        word = pool[at + ((unsigned)j >> 3)];
-                const unsigned i = valid ? (unsigned)word & 0xffu : 0u;
-                word >>= 8;
+                if (__any(valid && pooled && (j & per_mask) == 0))
+                    if (valid && pooled && (j & per_mask) == 0)
+                        word = pool[at + ((unsigned)j >> per_shift)];
+                const unsigned i = valid ? (unsigned)word & entry_mask : 0u;
+                word >>= list_bits;
                 unsigned sign;
                 if (ANY_HIT && fixed)
                 {
@@ -294,8 +297,8 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
                 }
                 if (valid && (!flt.ok || !(sign >> 31)))
                 {
-                    over = over || nk == 8;
-                    kept |= nk < 8 ? (unsigned long long)i << (8 * nk) : 0ull;
+                    over = over || nk > per_mask;
+                    kept |= nk <= per_mask ? (unsigned long long)i << (list_bits * nk) : 0ull;
                     nk++;
                 }
             }
@@ -312,11 +315,11 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         {
             phase2_rounds++;
             const bool valid = k < count;
-            if (__any(valid && pooled && (k & 7) == 0))
-                if (valid && pooled && (k & 7) == 0)
-                    cur = pool[at + ((unsigned)k >> 3)];
-            const int i = valid ? (int)((unsigned)cur & 0xffu) : 0;
-            cur >>= 8;
+            if (__any(valid && pooled && (k & per_mask) == 0))
+                if (valid && pooled && (k & per_mask) == 0)
+                    cur = pool[at + ((unsigned)k >> per_shift)];
+            const int i = valid ? (int)((unsigned)cur & entry_mask) : 0;
+            cur >>= list_bits;
             k++;
             if (exact_step<ANY_HIT>(L, o, d, a, i, valid, best))
                 count = 0;
@@ -487,9 +490,9 @@ TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridVi
         tally.swept++;
     PathHit r;
 #if TRT_STAMP
-    r.ph = trace<false>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, stamp_sum, &stamp_prev, 2);
+    r.ph = trace<false>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, grids.list_bits, stamp_sum, &stamp_prev, 2);
 #else
-    r.ph = trace<false>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool);
+    r.ph = trace<false>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, grids.list_bits);
 #endif
     r.hit = alive && r.ph.i >= 0;
     r.sky = alive && r.ph.i < 0;
@@ -553,9 +556,9 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
             TRT_STAMP_AT(8); // look-up
 #if TRT_STAMP
             const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, L.cull_dir + li * cull.padded, use_list, cell, grids.pool,
-                                       stamp_sum, &stamp_prev, 9);
+                                       grids.list_bits, stamp_sum, &stamp_prev, 9);
 #else
-            const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, L.cull_dir + li * cull.padded, use_list, cell, grids.pool);
+            const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, L.cull_dir + li * cull.padded, use_list, cell, grids.pool, grids.list_bits);
 #endif
             is_lit = sh.i < 0;
             factor = min1(dot(normal, sd));
@@ -585,9 +588,9 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
                 tally.swept++;
             TRT_STAMP_AT(14); // unit(to_light), strength, look-up
 #if TRT_STAMP
-            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool, stamp_sum, &stamp_prev, 15);
+            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool, grids.list_bits, stamp_sum, &stamp_prev, 15);
 #else
-            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool);
+            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool, grids.list_bits);
 #endif
             is_lit = sh.i < 0;
             // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the

@@ -126,12 +126,12 @@ static tables *build(const double *spheres, int n, const double *ground, const d
 #pragma omp critical
                 {
                     at = T->pool_words;
-                    room = at + (size_t)(count + 7) / 8 <= T->pool_cap;
+                    room = at + (size_t)trt_list_pool_words(count, 8) <= T->pool_cap;
                     if (room)
-                        T->pool_words += (size_t)(count + 7) / 8;
+                        T->pool_words += (size_t)trt_list_pool_words(count, 8);
                 }
             }
-            out[c] = trt_list_pack(masks + c * words, words, count, room ? T->pool : NULL, (unsigned)at);
+            out[c] = trt_list_pack(masks + c * words, words, count, room ? T->pool : NULL, (unsigned)at, 8);
         }
         free(cones);
         free(masks);
@@ -162,7 +162,7 @@ static int in_list(const tables *T, unsigned long long cell, int sphere)
     int prev = -1;
     for (int k = 0; k < e; k++)
     {
-        const int i = trt_list_entry(cell, T->pool, k);
+        const int i = trt_list_entry(cell, T->pool, k, 8);
         if (i <= prev)
             return -2; /* not ascending: a malformed list */
         prev = i;

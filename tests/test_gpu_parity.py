@@ -571,6 +571,27 @@ def test_path_ray_tables_never_change_a_frame(ctx, cells):
         ctx.set_path_grids(64, 32)
 
 
+@pytest.mark.parametrize("n", [257, 300, 700])
+def test_scenes_of_more_than_256_spheres_keep_their_light_tables(ctx, n):
+    """List cells index spheres with one byte up to 256 spheres; larger scenes use 16-bit entries for the light tables and sweep
+    for their path rays (no family tables).  Frames and trace counts against the oracle, tables on / coarse / off."""
+    scene = S.synth_scene(n, T.sky("synth"), T.bench_camera(72, 40, 2.5), seed=11)
+    want, st = T.oracle_render(scene, 72, 40, 6, 4)
+    ctx.enable_counters(True)
+    try:
+        for cells in ((128, 64), (9, 3), (0, 0)):
+            ctx.set_light_grids(*cells)
+            got = render(ctx, scene, 72, 40, 6, 4)
+            assert np.array_equal(bits(got), bits(want)), (n, cells)
+            assert ctx.read_counters() == (st.path_rays, st.shadow_rays)
+            diag = ctx.read_diagnostics()
+            if cells == (128, 64):  # the shadow traces read lists: fewer swept traces than path + shadow stages together
+                assert diag["swept_traces"] < 2 * diag["wave_loop_trips"], diag
+    finally:
+        ctx.enable_counters(False)
+        ctx.set_light_grids(128, 64)
+
+
 def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
     """The library forms the families' cones and marks and packs the cells on the GPU; tests/test_raygrid.py proves the HOST
     builder conservative.  Both run the same predicates (+ - * / sqrt only), so every cell must list the same spheres."""
