@@ -71,8 +71,8 @@ int trt_emitter_write(const trt_emitter *e, FILE *stream);
 int trt_draw_screen(const Screen *screen, FILE *stream);
 
 /* ---- frame fingerprint ------------------------------------------------------------------ */
-/* FNV-1a-64 (offset 1469598103934665603, prime 1099511628211) over raw bytes: the hash the golden frames are recorded
- * with, e.g. over screen->pixels[0 .. W*H) after project_scene (TRT.c:966). */
+/* FNV-1a-64 with the offset SURVEY.md 8c states, 1469598103934665603 (NOT the textbook 14695981039346656037), and prime
+ * 1099511628211, over raw bytes: the hash the golden frames are recorded with, e.g. over screen->pixels[0 .. W*H) after project_scene (TRT.c:966). */
 unsigned long long trt_fnv1a64(const void *data, size_t bytes);
 
 #ifdef __cplusplus

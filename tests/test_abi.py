@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 import support as T
@@ -24,6 +25,25 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(dll, name), f"{name} declared in include/trt_hip.h but not exported"
     assert set(declared) == set(hip.SYMBOLS), set(declared) ^ set(hip.SYMBOLS)
+
+
+def test_library_exports_every_host_side_symbol():
+    """include/trt_host.h: camera orbit, PPM / cubemap loader, emitter, frame fingerprint -- host C in the same library"""
+    from terminalraytracer_amd import host
+    text = open(os.path.join(T.ROOT, "include", "trt_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(trt_[a-z0-9_]+)\s*\(", text)))
+    dll = host.lib()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(dll, name), f"{name} declared in include/trt_host.h but not exported"
+    assert set(declared) == set(host.HOST_SYMBOLS), set(declared) ^ set(host.HOST_SYMBOLS)
+    # the fingerprint is FNV-1a-64 as SURVEY 8c states it
+    assert host.fnv1a64(np.frombuffer(b"", dtype=np.uint8)) == f"{1469598103934665603:016x}"
+    h = 1469598103934665603  # SURVEY's offset (not the textbook 14695981039346656037): the goldens are recorded with it
+    for byte in b"TerminalRayTracer":
+        h = ((h ^ byte) * 1099511628211) % (1 << 64)
+    assert host.fnv1a64(np.frombuffer(b"TerminalRayTracer", dtype=np.uint8)) == f"{h:016x}"
 
 
 def test_version_and_error_strings():
