@@ -592,6 +592,70 @@ def test_scenes_of_more_than_256_spheres_keep_their_light_tables(ctx, n):
         ctx.set_light_grids(128, 64)
 
 
+def _degenerate_scenes():
+    base = S.synth_scene(24, T.sky("synth"), T.bench_camera(40, 24, 2.5), seed=3)
+
+    def with_ground(point=None, normal=None, refl=None):
+        g = base.ground.copy()
+        if point is not None:
+            g[0:3] = point
+        if normal is not None:
+            g[3:6] = normal
+        if refl is not None:
+            g[9] = g[14] = refl
+        return S.SceneData(base.spheres, g, base.dir_lights, base.point_lights, base.camera, base.sky)
+
+    out = [("ground without a normal", with_ground(normal=[0.0, 0.0, 0.0])),
+           ("ground with a vanishing normal", with_ground(normal=[0.0, 1e-200, 0.0])),
+           ("ground with a huge normal", with_ground(normal=[0.0, 1e150, 1e150], refl=1.0)),
+           ("vertical mirror ground through the scene", with_ground(point=[0.3, 0.0, 0.0], normal=[1.0, 0.0, 0.0], refl=1.0))]
+    cam = base.camera.copy()
+    cam[10] = -2.0  # the eye exactly on the ground plane
+    out.append(("eye on the ground plane", base.with_camera(cam)))
+    cam = base.camera.copy()
+    cam[9:12] = base.spheres[5, :3]  # the eye at a sphere's centre
+    out.append(("eye at a sphere's centre", base.with_camera(cam)))
+    sph = base.spheres.copy()
+    sph[0, 3] = -0.4   # a negative radius (r*r is what the reference uses)
+    sph[1, 3] = 0.0
+    sph[2, :3] = [1e7, -3e6, 2e6]  # one sphere very far away: the tables' range explodes
+    sph[3, :3] = sph[4, :3]        # concentric twins with equal radii: exact ties
+    sph[3, 3] = sph[4, 3]
+    out.append(("odd radii, a far sphere, exact twins", base.with_spheres(sph)))
+    far = base.spheres.copy()
+    far[:, :3] = far[:, :3] * 1e5  # an enormous scene: hit points lose digits against the 1e-6 nudge
+    far[:, 3] *= 1e5
+    gf = base.ground.copy()
+    gf[1] *= 1e5
+    cf = base.camera.copy()
+    cf[9:12] *= 1e5
+    out.append(("a scene 1e5 times larger", S.SceneData(far, gf, base.dir_lights, base.point_lights * np.array([1e5, 1e5, 1e5, 1, 1, 1, 1e10]), cf, base.sky)))
+    pl = base.point_lights.copy()
+    pl[0, :3] = base.camera[9:12]  # a light at the eye
+    out.append(("a light at the eye", S.SceneData(base.spheres, base.ground, base.dir_lights, pl, base.camera, base.sky)))
+    return out
+
+
+@pytest.mark.parametrize("name,scene", _degenerate_scenes(), ids=[n for n, _ in _degenerate_scenes()])
+def test_degenerate_scenes_match_the_oracle(ctx, name, scene):
+    """Inputs the candidate tables must survive: grounds whose mirror images are NaN or astronomically far, the eye on the
+    ground or at a sphere's centre, negative / zero radii, one sphere 1e7 away, exact twins, a scene 1e5 times larger, a
+    light at the eye.  NaN pixels must sit where the oracle's do; everything else bit for bit; counts equal."""
+    w, h, b, spp = 40, 24, 6, 3
+    with np.errstate(all="ignore"):
+        want, st = T.oracle_render(scene, w, h, b, spp)
+    ctx.enable_counters(True)
+    try:
+        for kernel in KERNELS:
+            got = render(ctx, scene, w, h, b, spp, kernel)
+            finite = np.isfinite(want)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (name, kernel)
+            assert np.array_equal(bits(got[finite]), bits(want[finite])), (name, kernel)
+            assert ctx.read_counters() == (st.path_rays, st.shadow_rays), (name, kernel)
+    finally:
+        ctx.enable_counters(False)
+
+
 def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
     """The library forms the families' cones and marks and packs the cells on the GPU; tests/test_raygrid.py proves the HOST
     builder conservative.  Both run the same predicates (+ - * / sqrt only), so every cell must list the same spheres."""
