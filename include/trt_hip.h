@@ -165,6 +165,18 @@ int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres);
 long trt_read_path_tables(trt_context *ctx, const Camera *camera, unsigned long long *cells, size_t capacity_cells,
                           unsigned long long *pool, size_t capacity_pool, long info[8]);
 
+/* EXTENSION, PARITY UNPINNED.  The reference has no refraction (Material is {color, reflectivity, specularity},
+ * TRT.c:114-119, and only the near root of a sphere is ever used, TRT.c:657); BASELINE config 3 names "refractive
+ * materials" all the same.  ior[i] > 0 makes sphere i of the current scene a refractor with that index of refraction
+ * (relative to the outside), 0 leaves it the reference's opaque sphere; the Material layout is untouched.  A path ray that
+ * hits a refractor from outside is shaded like any hit (lighting, weight *= reflectivity, one bounce) and continues along
+ * the refracted direction; inside, the sphere is met at its far root; leaving it adds no colour and no weight but costs a
+ * bounce; total internal reflection mirrors the ray; shadow rays are the reference's.  count must equal the scene's
+ * sphere count when a frame is rendered; count = 0 turns the extension off.  Frames are checked bit for bit against
+ * oracle/trt_oracle.c's restatement of these very semantics -- not against the reference, which has none.  With the
+ * extension off (the default) a different kernel instantiation runs and nothing of this is on the path. */
+int trt_set_refraction(trt_context *ctx, const double *ior, int count);
+
 /* After trt_read_counters: the number of wave-level traces of the last counted frame in which some ray failed its table's
  * membership / range test and the whole wave swept the culling table instead (the slow path). */
 int trt_read_sweep_fallbacks(trt_context *ctx, unsigned long long *swept_traces);

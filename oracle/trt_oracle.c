@@ -459,6 +459,230 @@ void trt_oracle_project_scene(const Scene *scene, Screen *screen, int bounce_lim
                            rays_per_pixel, num_threads, stats);
 }
 
+/* ==================================================================================================================
+ * EXTENSION, PARITY UNPINNED: refraction.  The reference has no refraction (Material = {color, reflectivity,
+ * specularity}, TRT.c:114-119; BASELINE config 3 names "refractive materials" all the same).  What follows restates the
+ * semantics the HIP kernel's REFRACT variant implements (terminalraytracer_amd/csrc/trt_rounds.hpp), operation for
+ * operation, so that the GPU can be checked bit for bit against SOMETHING -- but that something is this file, not the
+ * reference.  With every index of refraction 0 it reduces to shade_pixel above.
+ *
+ *   ior[i] > 0 makes sphere i a refractor (index of refraction relative to the outside).  A path ray that hits it from
+ *   outside is shaded exactly as the reference shades a hit (lighting, weight *= reflectivity, one bounce) and continues
+ *   along the refracted direction from a point nudged 1e-6 PAST the surface; inside, the sphere itself is intersected with
+ *   the FAR root (the reference only ever uses the near root, TRT.c:657); leaving it adds no colour and no weight but costs
+ *   one bounce (so that a ray trapped by total internal reflection ends); total internal reflection mirrors the ray.
+ *   Shadow rays are the reference's: a refractor blocks light like any sphere.
+ * ================================================================================================================== */
+static inline int hit_sphere_far(v3 o, v3 d, const Sphere *s, v3 *p)
+{
+    v3 oc = {o.x - s->center.x, o.y - s->center.y, o.z - s->center.z};
+    double a = dot(d, d);
+    double b = 2.0 * dot(oc, d);
+    double c = dot(oc, oc) - s->radius * s->radius;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0)
+        return 0;
+    double t1 = (-b + sqrt(disc)) / (2.0 * a);
+    if (!(t1 > 0.0))
+        return 0;
+    p->x = o.x + t1 * d.x;
+    p->y = o.y + t1 * d.y;
+    p->z = o.z + t1 * d.z;
+    return 1;
+}
+
+typedef struct
+{
+    surface s;  /* as closest_hit returns it */
+    int sphere; /* index of the sphere that was hit, -1 otherwise */
+    v3 raw;     /* the hit point before the nudge */
+    v3 back;    /* the nudge vector: unit(o - raw) * 1e-6 */
+} surface_ext;
+
+static inline surface_ext closest_hit_ext(const Scene *scene, v3 o, v3 d, int inside)
+{
+    surface_ext r;
+    r.sphere = -1;
+    r.raw = o;
+    r.back = (v3){0.0, 0.0, 0.0};
+    surface best;
+    best.what = NONE;
+    double best_d2 = INFINITY;
+    v3 best_point = o, best_normal = d;
+    memset(&best.material, 0, sizeof best.material);
+    for (int i = 0; i < scene->num_spheres; i++)
+    {
+        const Sphere *s = &scene->spheres[i];
+        v3 p;
+        if (i == inside ? hit_sphere_far(o, d, s, &p) : hit_sphere(o, d, s, &p))
+        {
+            v3 back = sub(o, p);
+            double d2 = dot(back, back);
+            if (d2 < best_d2)
+            {
+                best.what = SPHERE;
+                best_d2 = d2;
+                best_point = p;
+                best_normal = sub(p, v3_ofp(&s->center));
+                best.material = s->material;
+                r.sphere = i;
+            }
+        }
+    }
+    {
+        v3 p;
+        if (hit_plane(o, d, &scene->ground, &p))
+        {
+            v3 back = sub(o, p);
+            double d2 = dot(back, back);
+            if (d2 < best_d2)
+            {
+                best.what = GROUND;
+                best_d2 = d2;
+                best_point = p;
+                best_normal = v3_of(&scene->ground.normal);
+                int odd = (int)(floor(p.x) + floor(p.z)) & 1;
+                best.material = odd ? scene->ground.odd_material : scene->ground.even_material;
+                r.sphere = -1;
+            }
+        }
+    }
+    if (best.what == NONE)
+    {
+        surface sky = closest_hit(scene, o, d, 1); /* a miss: exactly the reference's sky sample */
+        r.s = sky;
+        return r;
+    }
+    r.raw = best_point;
+    r.back = scale(unit(sub(o, best_point)), TRT_NUDGE);
+    best.point = add(best_point, r.back);
+    best.normal = unit(best_normal);
+    r.s = best;
+    return r;
+}
+
+static inline v3 shade_pixel_refractive(const Scene *scene, const double *ior, int width, int height, int row, int column, int bounce_limit,
+                                        int rays_per_pixel, trt_oracle_stats *st)
+{
+    const Camera *cam = &scene->camera;
+    v3 bx = v3_of(&cam->frame.basis.x), by = v3_of(&cam->frame.basis.y), bz = v3_of(&cam->frame.basis.z);
+    v3 eye = v3_ofp(&cam->frame.origin);
+    v3 mean = {0.0, 0.0, 0.0};
+    for (int k = 0; k < rays_per_pixel; k++)
+    {
+        double pixel_w = cam->screen_width / width;
+        double pixel_h = cam->screen_height / height;
+        double sx = (((double)column / (double)width) * cam->screen_width - cam->screen_width / 2.0);
+        double sy = -(((double)row / (double)height) * cam->screen_height - cam->screen_height / 2.0);
+        double sz = -cam->screen_distance;
+        sx += trt_oracle_triangle_wave(2 * TRT_PI * k / rays_per_pixel) / 2 * pixel_w;
+        sy += trt_oracle_triangle_wave(TRT_PI * k / rays_per_pixel) / 2 * pixel_h;
+        v3 dir = {0.0, 0.0, 0.0};
+        dir = add(dir, scale(bx, sx));
+        dir = add(dir, scale(by, sy));
+        dir = add(dir, scale(bz, sz));
+        dir = sub(dir, eye);
+        dir = unit(dir);
+        v3 org = eye;
+        v3 sample = {0.0, 0.0, 0.0};
+        int bounces = 0, inside = -1, going = 1;
+        double weight = 1.0, weight_sum = 0.0;
+        st->samples++;
+        while (going && bounces < bounce_limit && weight > 0.00001)
+        {
+            st->path_rays++;
+            surface_ext h = closest_hit_ext(scene, org, dir, inside);
+            const int leaving = h.s.what == SPHERE && h.sphere == inside;
+            if (!leaving)
+            { /* the reference's bounce, TRT.c:1026-1051 */
+                v3 color = v3_of(&h.s.material.color);
+                if (h.s.what != NONE)
+                    color = lit_color(scene, h.s.point, h.s.normal, color, st);
+                else
+                    st->sky_lookups++;
+                weight_sum += weight;
+                color = scale(color, weight);
+                if (h.s.what != NONE)
+                {
+                    weight *= h.s.material.reflectivity;
+                    bounces++;
+                }
+                else
+                {
+                    weight = 0.0;
+                    going = 0;
+                }
+                sample = add(sample, color);
+            }
+            else
+                bounces++; /* leaving a refractor: no colour, no weight */
+            int bent = 0;
+            if (h.s.what == SPHERE && ior[h.sphere] > 0.0)
+            {
+                const v3 nn = leaving ? scale(h.s.normal, -1.0) : h.s.normal; /* the normal facing the incoming ray */
+                const double cosi = -dot(nn, dir);
+                const double eta = leaving ? ior[h.sphere] : 1.0 / ior[h.sphere];
+                const double kk = 1.0 - (eta * eta) * (1.0 - cosi * cosi);
+                if (!(kk < 0.0))
+                {
+                    const double f = eta * cosi - sqrt(kk);
+                    v3 t = {eta * dir.x + f * nn.x, eta * dir.y + f * nn.y, eta * dir.z + f * nn.z};
+                    dir = unit(t);
+                    org = sub(h.raw, h.back); /* 1e-6 past the surface */
+                    inside = leaving ? -1 : h.sphere;
+                    bent = 1;
+                }
+                else
+                { /* total internal reflection: mirror about the facing normal, stay on this side */
+                    dir = unit(reflect(dir, nn));
+                    org = h.s.point;
+                    bent = 1;
+                }
+            }
+            if (!bent)
+            {
+                dir = unit(reflect(dir, h.s.normal)); /* TRT.c:1054-1056 */
+                org = h.s.point;
+            }
+        }
+        sample = scale(sample, 1.0 / weight_sum);
+        mean = add(mean, sample);
+    }
+    return scale(mean, 1.0 / rays_per_pixel);
+}
+
+void trt_oracle_project_scene_refractive(const Scene *scene, const double *ior, Screen *screen, int bounce_limit, int rays_per_pixel,
+                                         int num_threads, trt_oracle_stats *stats)
+{
+    unsigned long long n_path = 0, n_shadow = 0, n_sky = 0, n_samples = 0;
+    const int width = screen->width, height = screen->height;
+#ifdef _OPENMP
+    if (num_threads < 1)
+        num_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads) reduction(+ : n_path, n_shadow, n_sky, n_samples)
+#endif
+    for (int row = 0; row < height; row++)
+    {
+        trt_oracle_stats st = {0, 0, 0, 0};
+        for (int column = 0; column < width; column++)
+        {
+            v3 c = shade_pixel_refractive(scene, ior, width, height, row, column, bounce_limit, rays_per_pixel, &st);
+            v3_to(&screen->pixels[(size_t)row * width + column], c);
+        }
+        n_path += st.path_rays;
+        n_shadow += st.shadow_rays;
+        n_sky += st.sky_lookups;
+        n_samples += st.samples;
+    }
+    if (stats)
+    {
+        stats->path_rays = n_path;
+        stats->shadow_rays = n_shadow;
+        stats->sky_lookups = n_sky;
+        stats->samples = n_samples;
+    }
+}
+
 void trt_oracle_rgb8(const Vector *pixels, size_t count, unsigned char *rgb)
 {
     for (size_t i = 0; i < count; i++)

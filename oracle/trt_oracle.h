@@ -69,6 +69,12 @@ typedef struct
 } trt_oracle_ray_log;
 void trt_oracle_set_ray_log(trt_oracle_ray_log *log);
 
+/* EXTENSION, PARITY UNPINNED (the reference has no refraction): the semantics of the HIP kernel's refraction variant
+ * restated on the CPU, so that the GPU has something to be checked against bit for bit.  ior[i] > 0: sphere i refracts
+ * with that index (relative to the outside); 0: the reference's opaque sphere.  See the block comment in trt_oracle.c. */
+void trt_oracle_project_scene_refractive(const Scene *scene, const double *ior, Screen *screen, int bounce_limit, int rays_per_pixel,
+                                         int num_threads, trt_oracle_stats *stats);
+
 /* exact a/b and sqrt(a) tables for the device rounding self-test */
 void trt_oracle_div_sqrt(const double *a, const double *b, size_t n, double *quot, double *root);
 

@@ -141,6 +141,8 @@ struct trt_context
     std::vector<double> h_spheres, h_dir, h_point; // what the tables on the device were built from
     int grids_built_for[2] = {-1, -1};
     DeviceBuffer<uint32_t> d_sky;
+    DeviceBuffer<double> d_ior; // refraction extension: per sphere, > 0 = index of refraction
+    int ior_count = 0;          // 0 = off (the reference's path)
     DeviceBuffer<unsigned long long> d_counters;
     DeviceBuffer<unsigned int> d_queue;
     double *h_staging = nullptr; // pinned
@@ -695,6 +697,8 @@ static int init_context(trt_context *ctx)
     (void)hipFuncSetAttribute((const void *)trt::probe_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::probe_rounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     return TRT_OK;
 }
@@ -751,6 +755,7 @@ extern "C" int trt_destroy(trt_context *ctx)
     ctx->d_discs.release();
     ctx->d_cones.release();
     ctx->d_sky.release();
+    ctx->d_ior.release();
     ctx->d_counters.release();
     ctx->d_queue.release();
     if (ctx->h_staging)
@@ -832,6 +837,24 @@ extern "C" int trt_read_diagnostics(trt_context *ctx, unsigned long long *wave_l
         *wave_loop_trips = ctx->last_trips;
     if (phase2_rounds)
         *phase2_rounds = ctx->last_phase2;
+    return TRT_OK;
+}
+
+extern "C" int trt_set_refraction(trt_context *ctx, const double *ior, int count)
+{
+    if (!ctx || count < 0 || (count > 0 && !ior))
+        return fail(TRT_ERR_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->ior_count = 0;
+    if (count == 0)
+        return TRT_OK;
+    for (int i = 0; i < count; i++)
+        if (!(ior[i] >= 0.0) || !(ior[i] < 1e6))
+            return fail(TRT_ERR_ARGUMENT, "index of refraction %g of sphere %d", ior[i], i);
+    HIP_TRY(ctx->d_ior.reserve((size_t)count));
+    HIP_TRY(hipMemcpy(ctx->d_ior.ptr, ior, (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    ctx->ior_count = count;
     return TRT_OK;
 }
 
@@ -1084,7 +1107,17 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         const size_t plds = trt::rounds_lds_bytes(ctx->scene, rays_per_pixel);
         const dim3 grid(pl.grid), block(pl.block);
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
-        if (ctx->counters_enabled)
+        if (ctx->ior_count)
+        { // the refraction extension (parity unpinned): its own instantiation, the reference's path is not touched
+            if (ctx->ior_count != ctx->scene.num_spheres)
+                return fail(TRT_ERR_ARGUMENT, "trt_set_refraction was given %d indices, the scene has %d spheres", ctx->ior_count, ctx->scene.num_spheres);
+            f.ior = ctx->d_ior.ptr;
+            if (ctx->counters_enabled)
+                hipLaunchKernelGGL((trt::render_rounds_kernel<true, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
+            else
+                hipLaunchKernelGGL((trt::render_rounds_kernel<false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
+        }
+        else if (ctx->counters_enabled)
             hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         else
             hipLaunchKernelGGL((trt::render_rounds_kernel<false>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);

@@ -172,6 +172,7 @@ struct FrameView
     unsigned spp_magic;   // ceil(2^32 / spp): sample-unit index -> pixel
     double *samples;      // [pixels*spp][3] per-sample colours when the work units are samples
     double *out;          // compact framebuffer of the owned rows
+    const double *ior;    // refraction extension (render_rounds_kernel<.., true> only): per sphere, > 0 = index of refraction
     unsigned long long *counters; // [path, shadow] or nullptr
     unsigned int *queue;  // work-queue head for the persistent kernel
     int width, height;

@@ -180,18 +180,21 @@ struct Hit
 // One EXACT sphere test of TRT.c:638-672 in the reference's operation order, folded into the running closest hit of
 // TRT.c:808-826 (strict '<': the first index wins ties).  Predicated rather than branched: a lane without a candidate
 // (`valid` false) tests sphere 0 and discards the result.  Returns true when an ANY_HIT search is answered.
-template <bool ANY_HIT>
-TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool valid, Hit &best)
+// `inside` (refraction extension only, -1 otherwise): the sphere the ray travels inside of is met at the FAR root.
+template <bool ANY_HIT, bool REFRACT = false>
+TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool valid, Hit &best, int inside = -1)
 {
     const d3 c = d3{L.cx[i], L.cy[i], L.cz[i]};
     const d3 oc = sub(o, c);
     const double b = 2.0 * dot(oc, d);
     const double cc = dot(oc, oc) - L.r2[i];
     const double disc = b * b - 4.0 * a * cc;
+    const bool far_root = REFRACT && i == inside;
     bool done = false;
-    if (valid && !(disc < 0.0) && b < 0.0) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
+    if (valid && !(disc < 0.0) && (b < 0.0 || far_root)) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
     { // no further branches: selects keep `best` in place (nested ifs cost five register copies per level)
-        const double t0 = (-b - sqrt_exact(disc)) / (2.0 * a);
+        const double root = sqrt_exact(disc);
+        const double t0 = (far_root ? -b + root : -b - root) / (2.0 * a);
         const bool hit = t0 > 0.0;
         if (ANY_HIT)
         { // "anything in the way?" (TRT.c:908): the first hit answers it; its position is never used
@@ -227,9 +230,9 @@ TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool val
 #endif
 
 
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool REFRACT = false>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
-                  const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool, int list_bits
+                  const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool, int list_bits, int inside = -1
 #if TRT_STAMP
                   ,
                   unsigned long long *stamp_sum = nullptr, unsigned long long *stamp_prev_p = nullptr, int stamp_base = 0
@@ -321,7 +324,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
             const int i = valid ? (int)((unsigned)cur & entry_mask) : 0;
             cur >>= list_bits;
             k++;
-            if (exact_step<ANY_HIT>(L, o, d, a, i, valid, best))
+            if (exact_step<ANY_HIT, REFRACT>(L, o, d, a, i, valid, best, inside))
                 count = 0;
         }
     }
@@ -374,7 +377,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
                 const bool valid = cand != 0 && base + lead < n;
                 const int i = valid ? base + lead : 0;
                 cand &= ~(0x8000000000000000ull >> lead);
-                if (exact_step<ANY_HIT>(L, o, d, a, i, valid, best))
+                if (exact_step<ANY_HIT, REFRACT>(L, o, d, a, i, valid, best, inside))
                     cand = 0ull;
             }
         }
@@ -473,9 +476,9 @@ struct PathHit
 // (trt_raygrid.h) unless some lane's ray is not a member of its family; then the surface record.  `fam` becomes the family of
 // the NEXT path ray: it starts on the sphere that was hit, or it is the mirror image in the ground of a ray of this one's
 // family (a ray from the ground cannot hit the ground again; if it does, it has no family).
-template <bool COUNT>
+template <bool COUNT, bool REFRACT = false>
 TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridView &grids, int n, d3 o, d3 d, int &fam, bool alive, d3 gp, d3 gn,
-                           Tally &tally)
+                           Tally &tally, int inside = -1)
 {
     TRT_STAGE_STAMPS(tally);
     bool p_list = false;
@@ -490,9 +493,10 @@ TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridVi
         tally.swept++;
     PathHit r;
 #if TRT_STAMP
-    r.ph = trace<false>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, grids.list_bits, stamp_sum, &stamp_prev, 2);
+    r.ph = trace<false, REFRACT>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside, stamp_sum,
+                                 &stamp_prev, 2);
 #else
-    r.ph = trace<false>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, grids.list_bits);
+    r.ph = trace<false, REFRACT>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside);
 #endif
     r.hit = alive && r.ph.i >= 0;
     r.sky = alive && r.ph.i < 0;
@@ -556,7 +560,7 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
             TRT_STAMP_AT(8); // look-up
 #if TRT_STAMP
             const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, L.cull_dir + li * cull.padded, use_list, cell, grids.pool,
-                                       grids.list_bits, stamp_sum, &stamp_prev, 9);
+                                       grids.list_bits, -1, stamp_sum, &stamp_prev, 9);
 #else
             const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, L.cull_dir + li * cull.padded, use_list, cell, grids.pool, grids.list_bits);
 #endif
@@ -588,7 +592,7 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
                 tally.swept++;
             TRT_STAMP_AT(14); // unit(to_light), strength, look-up
 #if TRT_STAMP
-            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool, grids.list_bits, stamp_sum, &stamp_prev, 15);
+            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool, grids.list_bits, -1, stamp_sum, &stamp_prev, 15);
 #else
             const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool, grids.list_bits);
 #endif
@@ -629,7 +633,12 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
 #endif
 #endif
 
-template <bool COUNT>
+// REFRACT (EXTENSION, parity unpinned: the reference has no refraction): f.ior[i] > 0 makes sphere i a refractor.  A path
+// ray that hits it from outside is shaded like any hit and continues along the refracted direction from a point 1e-6 PAST
+// the surface; inside, that sphere is met at its far root; leaving it adds no colour and no weight but costs a bounce; total
+// internal reflection mirrors the ray.  Restated operation for operation in oracle/trt_oracle.c (shade_pixel_refractive).
+// The default instantiation (REFRACT = false) is the reference's path, unchanged.
+template <bool COUNT, bool REFRACT = false>
 __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -650,6 +659,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
     d3 o = d3{0.0, 0.0, 0.0}, d = d3{0.0, 0.0, -1.0}; // the pending path ray
     d3 next_dir = d;                                  // un-normalised direction of the next path ray
     int fam = 0;                                      // family of the pending path ray (trt_raygrid.h): 0 = it starts at the eye
+    int inside = -1;                                  // REFRACT: the refractor the pending ray travels inside of
     Tally tally;
     unsigned pool_next = 0, pool_end = 0; // wave-uniform: units fetched from the queue, not yet handed out
 
@@ -711,6 +721,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                         next_dir = sub(dir, load3(L.cam + 9)); // sic, TRT.c:1005
                         o = load3(L.cam + 9);
                         fam = 0;
+                        inside = -1;
                         sample = d3{0.0, 0.0, 0.0};
                         weight = 1.0;
                         weight_sum = 0.0;
@@ -731,8 +742,10 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
         if (COUNT && alive)
             tally.path++;
         TRT_STAMP_AT(1); // unit(next_dir)
-        const PathHit hit = path_stage<COUNT>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally);
-        const bool path_hit = hit.hit, path_sky = hit.sky;
+        const PathHit hit = path_stage<COUNT, REFRACT>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside);
+        // REFRACT: the ray leaves the refractor it was inside of -- no shading, no weight, one bounce
+        const bool leaving = REFRACT && hit.hit && hit.ph.i == inside;
+        const bool path_hit = hit.hit && !leaving, path_sky = hit.sky;
         const d3 h_normal = hit.normal;
         const int h_mat = hit.mat;
         bool end_sample = false;
@@ -744,15 +757,56 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             sample = add(sample, scale(color, weight));
             end_sample = true;
         }
-        if (path_hit)
+        d3 lit;
+        if (!REFRACT)
         {
-            next_dir = reflect(d, h_normal);              // TRT.c:1054, normalised at the top of the next round
-            o = add(hit.ph.p, scale(hit.back, 0.000001)); // TRT.c:873-874; origin of the shadow rays and of the next path ray
+            if (path_hit)
+            {
+                next_dir = reflect(d, h_normal);              // TRT.c:1054, normalised at the top of the next round
+                o = add(hit.ph.p, scale(hit.back, 0.000001)); // TRT.c:873-874; origin of the shadow rays and of the next path ray
+            }
+            TRT_STAMP_AT(7); // P post: sky texel, reflection, nudge
+            // ===================================== S(i): shadow rays =====================================
+            lit = shadow_stage<COUNT>(L, cull, grids, n, nd, nl, o, h_normal, h_mat, path_hit, gp, gn, tally);
         }
-
-        TRT_STAMP_AT(7); // P post: sky texel, reflection, nudge
-        // ======================================= S(i): shadow rays =======================================
-        const d3 lit = shadow_stage<COUNT>(L, cull, grids, n, nd, nl, o, h_normal, h_mat, path_hit, gp, gn, tally);
+        else
+        {
+            const d3 shade_at = add(hit.ph.p, scale(hit.back, 0.000001)); // TRT.c:873-874: where the surface is lit; origin of a reflected ray
+            if (hit.hit)
+            {
+                bool bent = false;
+                if (hit.ph.i < n)
+                {
+                    const double ior = f.ior[hit.ph.i];
+                    if (ior > 0.0)
+                    {
+                        const d3 nn = leaving ? scale(h_normal, -1.0) : h_normal; // the normal facing the incoming ray
+                        const double cosi = -dot(nn, d);
+                        const double eta = leaving ? ior : 1.0 / ior;
+                        const double kk = 1.0 - (eta * eta) * (1.0 - cosi * cosi);
+                        bent = true;
+                        if (!(kk < 0.0))
+                        {
+                            const double fac = eta * cosi - __builtin_sqrt(kk);
+                            next_dir = d3{eta * d.x + fac * nn.x, eta * d.y + fac * nn.y, eta * d.z + fac * nn.z};
+                            o = sub(hit.ph.p, scale(hit.back, 0.000001)); // 1e-6 past the surface
+                            inside = leaving ? -1 : hit.ph.i;
+                        }
+                        else
+                        { // total internal reflection: mirror about the facing normal, stay on this side
+                            next_dir = reflect(d, nn);
+                            o = shade_at;
+                        }
+                    }
+                }
+                if (!bent)
+                {
+                    next_dir = reflect(d, h_normal);
+                    o = shade_at;
+                }
+            }
+            lit = shadow_stage<COUNT>(L, cull, grids, n, nd, nl, shade_at, h_normal, h_mat, path_hit, gp, gn, tally);
+        }
 
         TRT_STAMP_AT(20); // lit accumulate
         // ======================================= END of the bounce =======================================
@@ -766,6 +820,13 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             if (bounces < f.bounce_limit && weight > 0.00001) // TRT.c:1018
                 weight_sum = weight_sum_new;
             else
+                end_sample = true;
+        }
+        if (REFRACT && leaving)
+        {
+            bounces++;
+            weight_sum_new = weight_sum; // nothing was contributed
+            if (!(bounces < f.bounce_limit))
                 end_sample = true;
         }
         if (__any(end_sample))

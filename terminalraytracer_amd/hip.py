@@ -72,6 +72,7 @@ SYMBOLS = {
     "trt_set_path_grids_min_spheres": (_I, [_VP, _I]),
     "trt_read_path_tables": (C.c_long, [_VP, C.POINTER(L.Camera), _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_long)]),
     "trt_read_sweep_fallbacks": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
+    "trt_set_refraction": (_I, [_VP, _VP, _I]),
     "trt_reserve_cus": (_I, [_VP, _I]),
     "trt_get_stream": (_I, [_VP, C.POINTER(C.c_void_p)]),
     "trt_selftest_unit": (_I, [_VP, _VP, C.c_size_t, _VP, _VP]),
@@ -203,6 +204,14 @@ class Context:
             _check(int(got))
         keys = ("enabled", "eye_cells", "sphere_cells", "spheres", "cells", "pool_used_scene", "pool_used_eye", "pool_capacity")
         return dict(zip(keys, [int(x) for x in info])), cells[:got], pool
+
+    def set_refraction(self, ior=None):
+        """EXTENSION, parity unpinned: per-sphere indices of refraction (0 = opaque); None turns it off (trt_set_refraction)"""
+        if ior is None:
+            _check(lib().trt_set_refraction(self._h, None, 0))
+        else:
+            a = np.ascontiguousarray(ior, dtype=np.float64)
+            _check(lib().trt_set_refraction(self._h, a.ctypes.data, a.size))
 
     def read_sweep_fallbacks(self):
         v = C.c_ulonglong()

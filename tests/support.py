@@ -51,6 +51,9 @@ def oracle():
     lib.trt_oracle_fnv1a64.restype = C.c_ulonglong
     lib.trt_oracle_div_sqrt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     lib.trt_oracle_div_sqrt.restype = None
+    lib.trt_oracle_project_scene_refractive.argtypes = [C.POINTER(L.Scene), C.c_void_p, C.POINTER(L.Screen), C.c_int, C.c_int, C.c_int,
+                                                        C.POINTER(OracleStats)]
+    lib.trt_oracle_project_scene_refractive.restype = None
     return lib
 
 
@@ -72,6 +75,18 @@ def oracle_render(scene_data, width, height, bounce_limit, rays_per_pixel, threa
     px = np.zeros((r1 - r0, width, 3), dtype=np.float64)
     oracle().trt_oracle_render_rows(C.byref(scene), px.ctypes.data, width, height, r0, r1, bounce_limit, rays_per_pixel,
                                     threads, C.byref(st))
+    return px, st
+
+
+def oracle_render_refractive(scene_data, ior, width, height, bounce_limit, rays_per_pixel, threads=None):
+    """EXTENSION, parity unpinned: the oracle's restatement of the refraction variant (not the reference, which has none)."""
+    threads = threads or min(8, os.cpu_count() or 1)
+    scene = scene_data.as_scene()
+    ior = np.ascontiguousarray(ior, dtype=np.float64)
+    assert ior.size == scene_data.num_spheres
+    st = OracleStats()
+    screen, px = S.new_screen(width, height)
+    oracle().trt_oracle_project_scene_refractive(C.byref(scene), ior.ctypes.data, C.byref(screen), bounce_limit, rays_per_pixel, threads, C.byref(st))
     return px, st
 
 

@@ -656,6 +656,46 @@ def test_degenerate_scenes_match_the_oracle(ctx, name, scene):
         ctx.enable_counters(False)
 
 
+@pytest.mark.parametrize("tables", [(64, 32), (0, 0)], ids=["tables", "sweep"])
+def test_refraction_extension_matches_its_cpu_restatement(ctx, tables):
+    """EXTENSION, PARITY UNPINNED: the reference has no refraction (TRT.c:114-119, :657), so there is nothing of the reference's
+    to compare with.  trt_set_refraction selects another instantiation of the production kernel; its frames must equal
+    oracle/trt_oracle.c's restatement of the same semantics bit for bit (glass of index 1.5, an index below 1 with total
+    reflection from outside, index 1, nested and touching refractors, a refractor on the floor), the trace counts too;
+    with every index 0, and with the extension switched off again, the frame must be the reference path's."""
+    base = S.synth_scene(24, T.sky("synth"), T.bench_camera(96, 54, 2.5), seed=3)
+    sph = base.spheres.copy()
+    sph[5, :3] = sph[4, :3]
+    sph[5, 3] = sph[4, 3] * 0.5                     # a sphere nested in a refractor
+    sph[7, :3] = sph[6, :3] + [sph[6, 3] + sph[7, 3], 0.0, 0.0]  # touching
+    sph[9, 1] = -2.0 + sph[9, 3] * 0.8              # one that dips into the floor
+    scene = base.with_spheres(sph)
+    ior = np.where(np.arange(24) % 3 == 0, 1.5, 0.0)
+    ior[1], ior[2], ior[4], ior[7] = 0.7, 1.0, 1.33, 2.4
+    w, h, b, spp = 96, 54, 10, 4
+    try:
+        ctx.set_path_grids(*tables)
+        plain, _ = T.oracle_render(scene, w, h, b, spp)
+        want, st = T.oracle_render_refractive(scene, ior, w, h, b, spp)
+        assert (want != plain).any()
+        ctx.enable_counters(True)
+        ctx.set_refraction(ior)
+        got = render(ctx, scene, w, h, b, spp)
+        assert np.array_equal(bits(got), bits(want))
+        assert ctx.read_counters() == (st.path_rays, st.shadow_rays)
+        ctx.set_refraction(np.zeros(24))
+        assert np.array_equal(bits(render(ctx, scene, w, h, b, spp)), bits(plain))
+        ctx.set_refraction(ior[:5])  # the wrong number of indices for this scene
+        with pytest.raises(hip.TrtError):
+            render(ctx, scene, w, h, b, spp)
+        ctx.set_refraction(None)
+        assert np.array_equal(bits(render(ctx, scene, w, h, b, spp)), bits(plain))
+    finally:
+        ctx.enable_counters(False)
+        ctx.set_refraction(None)
+        ctx.set_path_grids(64, 32)
+
+
 def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
     """The library forms the families' cones and marks and packs the cells on the GPU; tests/test_raygrid.py proves the HOST
     builder conservative.  Both run the same predicates (+ - * / sqrt only), so every cell must list the same spheres."""
