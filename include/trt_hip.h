@@ -248,6 +248,9 @@ int trt_dist_render(trt_dist *d, const Camera *camera, int bounce_limit, int ray
 int trt_dist_synchronize(trt_dist *d);
 /* synchronise, then copy an assembled frame into screen->pixels-like host memory (width*height Vectors) */
 int trt_dist_fetch(trt_dist *d, const void *d_frame, Vector *pixels);
+/* The root's assembly map, pure host arithmetic (no GPU): source_row[frame row] = row of the rank-major gather buffer in
+ * which rank r's shard starts at row r * max_rows.  Returns max_rows, the height every shard is padded to. */
+int trt_dist_source_rows(int width, int height, int tile_rows, int world, int *source_row);
 int trt_dist_info(const trt_dist *d, int *rank, int *world, int *local_rows, int *max_rows, int *frames_in_flight);
 /* the renderer context of a slot (counters, kernel times, kernel selection); owned by d */
 trt_context *trt_dist_context(trt_dist *d, int slot);

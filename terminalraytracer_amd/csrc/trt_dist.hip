@@ -152,6 +152,38 @@ struct trt_dist
 
 extern "C" const char *trt_dist_last_error(void) { return g_dist_error; }
 
+// The root's assembly map (pure host arithmetic, no GPU): frame row -> row of the rank-major gather buffer in which rank r's
+// shard starts at row r * max_rows.  Returns max_rows (the padded shard height), or a negative TRT_ERR_*.
+extern "C" int trt_dist_source_rows(int width, int height, int tile_rows, int world, int *source_row)
+{
+    if (width < 1 || height < 1 || tile_rows < 1 || world < 1 || !source_row)
+        return dist_fail(TRT_ERR_ARGUMENT, "bad argument");
+    int max_rows = 0;
+    for (int r = 0; r < world; r++)
+    {
+        const trt_rowset rs = {width, height, tile_rows, r, world};
+        max_rows = std::max(max_rows, trt_rowset_rows(&rs));
+    }
+    for (int row = 0; row < height; row++)
+        source_row[row] = -1;
+    for (int r = 0; r < world; r++)
+    {
+        const trt_rowset rs = {width, height, tile_rows, r, world};
+        const int rows = trt_rowset_rows(&rs);
+        for (int i = 0; i < rows; i++)
+        {
+            const int at = trt_rowset_frame_row(&rs, i);
+            if (at < 0 || at >= height || source_row[at] != -1)
+                return dist_fail(TRT_ERR_ARGUMENT, "the row tiles do not partition the frame");
+            source_row[at] = r * max_rows + i;
+        }
+    }
+    for (int row = 0; row < height; row++)
+        if (source_row[row] < 0)
+            return dist_fail(TRT_ERR_ARGUMENT, "the row tiles do not cover the frame");
+    return max_rows;
+}
+
 extern "C" int trt_dist_unique_id(void *id_out)
 {
     if (!id_out)
@@ -290,15 +322,8 @@ extern "C" int trt_dist_create(int device, const Scene *scene, const void *id, i
         if (rank == d->root)
         { // frame row -> row of the rank-major gather buffer (the tile map of trt_rowset_frame_row)
             std::vector<int> source((size_t)height, -1);
-            for (int r2 = 0; r2 < world; r2++)
-            {
-                const trt_rowset rs = {width, height, tile_rows, r2, world};
-                for (int i = 0; i < d->rows_of_rank[(size_t)r2]; i++)
-                    source[(size_t)trt_rowset_frame_row(&rs, i)] = r2 * d->max_rows + i;
-            }
-            for (int v : source)
-                if (v < 0)
-                    return bail(dist_fail(TRT_ERR_ARGUMENT, "the row tiles do not cover the frame"));
+            if (trt_dist_source_rows(width, height, tile_rows, world, source.data()) != d->max_rows)
+                return bail(dist_fail(TRT_ERR_ARGUMENT, "the row tiles do not cover the frame"));
             DIST_HIP_B(hipMalloc((void **)&d->d_source_row, source.size() * sizeof(int)));
             DIST_HIP_B(hipMemcpy(d->d_source_row, source.data(), source.size() * sizeof(int), hipMemcpyHostToDevice));
         }

@@ -87,6 +87,7 @@ SYMBOLS = {
     "trt_dist_render": (_I, [_VP, C.POINTER(L.Camera), _I, _I, C.POINTER(_VP)]),
     "trt_dist_synchronize": (_I, [_VP]),
     "trt_dist_fetch": (_I, [_VP, _VP, _VP]),
+    "trt_dist_source_rows": (_I, [_I, _I, _I, _I, C.POINTER(_I)]),
     "trt_dist_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
     "trt_dist_context": (_VP, [_VP, _I]),
     "trt_dist_destroy": (_I, [_VP]),

@@ -66,6 +66,27 @@ def test_rowsets_partition_the_frame(w, h, tile, world):
     assert sorted(seen) == list(range(h))  # every row exactly once
 
 
+@pytest.mark.parametrize("w,h,tile,world", [(1920, 1080, 8, 8), (1920, 1080, 8, 3), (3840, 2160, 8, 8), (67, 13, 4, 3), (5, 2, 8, 4), (16, 9, 1, 4)])
+def test_dist_assembly_map_puts_every_ranks_rows_in_frame_order(w, h, tile, world):
+    """trt_dist's root gathers the ranks' compact shards rank-major (each padded to the largest shard) and one kernel copies
+    row source_row[r] of that buffer to frame row r.  Here the ranks' shards are simulated on the CPU: shard rows carry their
+    frame row number, and the map must put them back in order (what test_gpu_parity checks on the GPU for one rank)."""
+    lib = hip.lib()
+    source = (C.c_int * h)()
+    max_rows = lib.trt_dist_source_rows(w, h, tile, world, source)
+    assert max_rows > 0
+    gathered = np.full(world * max_rows, -1, dtype=np.int64)
+    for rank in range(world):
+        rs = hip.RowSet.shard(w, h, rank, world, tile)
+        n = lib.trt_rowset_rows(C.byref(rs))
+        assert n <= max_rows
+        for i in range(n):
+            gathered[rank * max_rows + i] = lib.trt_rowset_frame_row(C.byref(rs), i)  # what rank `rank` sends as its row i
+    frame = gathered[np.array(list(source))]
+    assert np.array_equal(frame, np.arange(h))
+    assert lib.trt_dist_source_rows(w, h, 0, world, source) < 0
+
+
 def test_rowset_rejects_nonsense():
     lib = hip.lib()
     for bad in (hip.RowSet(0, 10, 1, 0, 1), hip.RowSet(10, 10, 0, 0, 1), hip.RowSet(10, 10, 1, -1, 1),
