@@ -31,18 +31,14 @@ HOST_SYMBOLS = {
     "trt_draw_screen": (_I, [C.POINTER(L.Screen), _VP]),
     "trt_fnv1a64": (C.c_ulonglong, [_VP, C.c_size_t]),
 }
-_bound = False
-
-
 def lib():
-    global _bound
     dll = _lib()
-    if not _bound:
+    if not getattr(dll, "_trt_host_bound", False):  # per library object: hip.lib() may have been reloaded
         for name, (res, args) in HOST_SYMBOLS.items():
             fn = getattr(dll, name)
             fn.restype = res
             fn.argtypes = args
-        _bound = True
+        dll._trt_host_bound = True
     return dll
 
 
