@@ -53,7 +53,9 @@ def light_heavy_scene(rng, w, h):
 
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
-make = {"wide": wide_scene, "lights": light_heavy_scene}.get(sys.argv[3] if len(sys.argv) > 3 else "", P._fuzz_scene)
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
+make = {"wide": wide_scene, "lights": light_heavy_scene}.get(mode, P._fuzz_scene)
+refract = mode == "refract"  # EXTENSION, parity unpinned: against the oracle's restatement of the extension, not the reference
 bad = 0
 with hip.Context(0) as ctx:
     for seed in range(first, first + count):
@@ -61,8 +63,15 @@ with hip.Context(0) as ctx:
         w, h = int(rng.integers(8, 160)), int(rng.integers(4, 90))
         b, spp = int(rng.integers(1, 13)), int(rng.choice([1, 3, 10]))
         scene = make(rng, w, h)
+        ior = None
+        if refract and len(scene.spheres):
+            ior = rng.choice([0.0, 0.0, 1.5, 1.33, 2.4, 1.0, 0.7], len(scene.spheres))
+        ctx.set_refraction(ior)
         with np.errstate(all="ignore"):
-            want, st = T.oracle_render(scene, w, h, b, spp)
+            if ior is not None:
+                want, st = T.oracle_render_refractive(scene, ior, w, h, b, spp)
+            else:
+                want, st = T.oracle_render(scene, w, h, b, spp)
         got = P.render(ctx, scene, w, h, b, spp)
         finite = np.isfinite(want)
         ok = np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(P.bits(got[finite]), P.bits(want[finite]))

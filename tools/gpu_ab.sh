@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for r in 1 2; do
-for lib in terminalraytracer_amd/libtrt_hip.so build/aos.so; do
+for lib in terminalraytracer_amd/libtrt_hip.so build/mat6.so; do
   for mode in "" "--animation 60"; do
   TRT_HIP_LIB=$PWD/$lib timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 20 $mode 2>/dev/null | python3 -c "
 import json,sys
