@@ -337,7 +337,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (prof or {}).get("hbm_bytes_per_launch"),
                          "traffic_source": (prof or {}).get("source"),
-                         "algorithmic_bytes": alg, "kernel": "render_rounds_kernel<false>", "kernel_ms": render_ms_avg,
+                         "algorithmic_bytes": alg, "kernel": "render_rounds_kernel<false, false>", "kernel_ms": render_ms_avg,
                          "achieved_by_step": alg / (ms_step * 1e-3) / 1e9,
                          "note": "achieved = algorithmic bytes of a frame (SURVEY 8d) / the render kernel's own average duration, HIP events "
                                  "on its stream, frames launched strictly one at a time (one_frame_at_a_time); the timed region keeps "
