@@ -158,6 +158,14 @@ int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_cells);
  * sphere are cheaper than a look-up with its membership test (default 12; 0 = tables for every scene). */
 int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres);
 
+/* Shading decoupled from the lane that owns the sample (render_rounds_kernel<.., .., true>): the hits of a
+ * wave become tasks in a ring in LDS and are shaded 64 at a time, whichever lanes they came from, so that the shadow rays run
+ * with ~95 % of the lanes busy instead of ~61 % (the share of path rays that hit something).  The ring costs about what one
+ * light's idle lanes cost: mode -1 (default) uses it for scenes with three lights or more, when the rings fit in LDS beside
+ * the scene without costing a resident wave; 0: never; 1: whenever the rings fit.  Frames are bit-identical in every mode.
+ * Environment TRT_COMPACTION=-1|0|1 sets the default of new contexts. */
+int trt_set_compaction(trt_context *ctx, int mode);
+
 /* Copy the path rays' tables to the host (tests: the device-built lists must equal the host reference builder's): list
  * cells (2*6*eye_cells^2, then 2N*6*sphere_cells^2) and the pool of long lists, as built for `camera`'s eye.
  * info: {enabled, eye_cells, sphere_cells, N, cells, pool words used by the scene's tables, by the eye's, pool capacity}.
@@ -180,6 +188,9 @@ int trt_set_refraction(trt_context *ctx, const double *ior, int count);
 /* After trt_read_counters: the number of wave-level traces of the last counted frame in which some ray failed its table's
  * membership / range test and the whole wave swept the culling table instead (the slow path). */
 int trt_read_sweep_fallbacks(trt_context *ctx, unsigned long long *swept_traces);
+/* Likewise: how many times a wave ran the shadow stage (over up to 64 hits each time).  hits / (64 * passes) is the lane
+ * activity of the shadow stage; the hits of a frame are shadow_rays / number of lights. */
+int trt_read_shading_passes(trt_context *ctx, unsigned long long *passes);
 
 /* Copy one light's table to the host (tests: the device-built table must equal the host reference builder's).
  * point_light: 0 = directional light `index`, 1 = point light `index`.  Returns the number of 64-bit words copied

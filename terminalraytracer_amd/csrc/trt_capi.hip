@@ -156,6 +156,8 @@ struct trt_context
 
     int kernel = 0; // 0 production (persistent waves, synchronous rounds), 1 reference-order
     int rounds_blocks_per_cu = 0;
+    int compact_blocks_per_cu = 0; // the same for the kernel with shading rings in LDS
+    int compaction = -1;           // trt_set_compaction: -1 when it costs no occupancy, 0 never, 1 whenever the rings fit
     size_t occupancy_for_lds = (size_t)-1;
     hipEvent_t ev_chunk[16]; // hand-over of framebuffer chunks to the host copy threads (trt_render_host)
     hipEvent_t ev_band[8];   // a band of rows is rendered: its copy-out may start (trt_render_host)
@@ -163,7 +165,7 @@ struct trt_context
     hipStream_t alt_stream = nullptr; // second render stream of trt_render_host: odd bands (their tails overlap the next band)
     hipEvent_t ev_fork = nullptr;
     bool counters_enabled = false;
-    unsigned long long last_trips = 0, last_phase2 = 0, last_swept = 0; // diagnostics of the counting kernel variant
+    unsigned long long last_trips = 0, last_phase2 = 0, last_swept = 0, last_passes = 0; // diagnostics of the counting kernel variant
 
     hipEvent_t ev_start[kEventRing], ev_mid[kEventRing], ev_stop[kEventRing]; // launch begins | render kernel done | reduction done
     long launches = 0;
@@ -176,6 +178,19 @@ struct trt_context
 
 namespace
 {
+
+constexpr int kCompactionMinLights = 3; // trt_set_compaction(-1): decouple the shading from three lights up
+
+// LDS of render_rounds_kernel<.., false, true>: the image, then one shading ring per wave of the workgroup
+size_t compact_ring_at(const trt::SceneView &s, int spp)
+{
+    return (trt::rounds_lds_bytes(s, spp) / sizeof(double) + 1) & ~(size_t)1; // in doubles, on a 16-byte boundary
+}
+
+size_t compact_lds_bytes(const trt::SceneView &s, int spp)
+{
+    return sizeof(double) * (compact_ring_at(s, spp) + (size_t)(trt::kCompactBlock / 64) * trt::kRingDoubles);
+}
 
 size_t scene_lds_bytes(const trt::SceneView &s)
 {
@@ -222,6 +237,7 @@ int upload_skybox(trt_context *ctx, const Skybox *sky)
     HIP_TRY(hipMemcpy(ctx->d_sky.ptr, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     ctx->scene.sky = ctx->d_sky.ptr;
     ctx->scene.sky_dim = dim;
+    ctx->scene.sky_dim_f = (double)dim;
     for (int f = 0; f < 6; f++)
         ctx->sky_faces[f] = sky->colors[f];
     ctx->sky_dim = dim;
@@ -556,6 +572,13 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
                                                              trt::rounds_lds_bytes(v, 64)));
         ctx->rounds_blocks_per_cu = std::max(blocks, 1);
         ctx->occupancy_for_lds = trt::rounds_lds_bytes(v, 64);
+        ctx->compact_blocks_per_cu = 0;
+        if (compact_lds_bytes(v, 64) <= (size_t)ctx->lds_limit)
+        {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false, false, true>, trt::kCompactBlock,
+                                                                 compact_lds_bytes(v, 64)));
+            ctx->compact_blocks_per_cu = blocks;
+        }
     }
     return TRT_OK;
 }
@@ -675,6 +698,12 @@ static int init_context(trt_context *ctx)
         if (sscanf(e, "%d,%d", &ge, &gs) == 2 && ge >= 0 && gs >= 0 && ge <= 1024 && gs <= 256)
             ctx->path_g_eye = ge, ctx->path_g_sph = gs;
     }
+    if (const char *e = getenv("TRT_COMPACTION"))
+    {
+        int mode = -1;
+        if (sscanf(e, "%d", &mode) == 1 && mode >= -1 && mode <= 1)
+            ctx->compaction = mode;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     for (int i = 0; i < kEventRing; i++)
@@ -698,6 +727,8 @@ static int init_context(trt_context *ctx)
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::probe_rounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     return TRT_OK;
@@ -866,11 +897,27 @@ extern "C" int trt_read_sweep_fallbacks(trt_context *ctx, unsigned long long *sw
     return TRT_OK;
 }
 
+extern "C" int trt_read_shading_passes(trt_context *ctx, unsigned long long *passes)
+{
+    if (!ctx || !passes)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    *passes = ctx->last_passes;
+    return TRT_OK;
+}
+
 extern "C" int trt_set_kernel(trt_context *ctx, int which)
 {
     if (!ctx || which < 0 || which > 1)
         return fail(TRT_ERR_ARGUMENT, "kernel %d", which);
     ctx->kernel = which;
+    return TRT_OK;
+}
+
+extern "C" int trt_set_compaction(trt_context *ctx, int mode)
+{
+    if (!ctx || mode < -1 || mode > 1)
+        return fail(TRT_ERR_ARGUMENT, "compaction mode %d", mode);
+    ctx->compaction = mode;
     return TRT_OK;
 }
 
@@ -994,6 +1041,7 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
     ctx->last_trips = c[2];
     ctx->last_phase2 = c[3];
     ctx->last_swept = c[28];
+    ctx->last_passes = c[29];
     if (getenv("TRT_PRINT_STAMPS"))
     { // diagnostic builds only (-DTRT_STAMP=1): per-stage wave-cycle sums
         static const char *const names[24] = {"units+primary", "unit(next_dir)", "P set-up", "P sweep", "P exact tests", "P plane",
@@ -1061,6 +1109,7 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
     f.row_y = ctx->d_axes.ptr + rows->width;
     f.inv_spp = 1.0 / rays_per_pixel;
     f.width_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rows->width - 1) / (unsigned)rows->width, 0xffffffffull);
+    f.tile_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rows->tile_rows - 1) / (unsigned)rows->tile_rows, 0xffffffffull);
     f.out = (double *)d_pixels;
     f.counters = ctx->counters_enabled ? ctx->d_counters.ptr : nullptr;
     f.queue = ctx->d_queue.ptr + 16 * lane_set; // a cache line apart
@@ -1102,8 +1151,21 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         HIP_TRY(scratch.reserve((size_t)units * 3));
         f.samples = scratch.ptr;
         f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
-        const trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0),
-                                                                      ctx->rounds_blocks_per_cu, units);
+        // shading decoupled from the owning lane (COMPACT, trt_rounds.hpp) when the rings fit in LDS: by default only if they
+        // cost no resident wave and the scene has lights enough to pay for them.
+        // Measured (profiles/r02/n_compaction.md): the ring costs what one light's idle lanes cost, so it is a wash with two
+        // lights and 5 / 7 / 11 / 14 % faster with 3 / 4 / 6 / 8.
+        const bool pays = ctx->scene.num_dir + ctx->scene.num_point >= kCompactionMinLights &&
+                          ctx->compact_blocks_per_cu * trt::kCompactBlock >= ctx->rounds_blocks_per_cu * trt::kPersistentBlock;
+        const bool compact = !ctx->ior_count && ctx->compact_blocks_per_cu > 0 && (ctx->compaction > 0 || (ctx->compaction < 0 && pays));
+        trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0),
+                                                                ctx->rounds_blocks_per_cu, units);
+        if (compact)
+        {
+            const long cap = (long)(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0)) * ctx->compact_blocks_per_cu;
+            const long want = (units + trt::kCompactBlock - 1) / trt::kCompactBlock;
+            pl = trt::PersistentLaunch{(unsigned)std::max(1L, std::min(want, cap)), (unsigned)trt::kCompactBlock};
+        }
         const size_t plds = trt::rounds_lds_bytes(ctx->scene, rays_per_pixel);
         const dim3 grid(pl.grid), block(pl.block);
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
@@ -1116,6 +1178,15 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
                 hipLaunchKernelGGL((trt::render_rounds_kernel<true, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
             else
                 hipLaunchKernelGGL((trt::render_rounds_kernel<false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
+        }
+        else if (compact)
+        {
+            f.ring_at = (unsigned)compact_ring_at(ctx->scene, rays_per_pixel);
+            const size_t clds = compact_lds_bytes(ctx->scene, rays_per_pixel);
+            if (ctx->counters_enabled)
+                hipLaunchKernelGGL((trt::render_rounds_kernel<true, false, true>), grid, block, clds, stream, ctx->scene, ctx->cull, f, ctx->grids);
+            else
+                hipLaunchKernelGGL((trt::render_rounds_kernel<false, false, true>), grid, block, clds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         }
         else if (ctx->counters_enabled)
             hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);

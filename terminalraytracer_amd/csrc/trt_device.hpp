@@ -159,6 +159,7 @@ struct SceneView
     int num_point;
     int sky_dim;
     double ground[16];
+    double sky_dim_f; // (double)sky_dim, formed once on the host (TRT.c:727-728 convert it per look-up: the same value)
 };
 
 struct FrameView
@@ -170,16 +171,30 @@ struct FrameView
     double inv_spp;       // 1.0 / rays_per_pixel (TRT.c:1065)
     unsigned width_magic; // ceil(2^32 / width): pixel index -> row by multiply-high (persistent kernel)
     unsigned spp_magic;   // ceil(2^32 / spp): sample-unit index -> pixel
+    unsigned tile_magic;  // ceil(2^32 / tile_rows): local row -> tile
     double *samples;      // [pixels*spp][3] per-sample colours when the work units are samples
     double *out;          // compact framebuffer of the owned rows
     const double *ior;    // refraction extension (render_rounds_kernel<.., true> only): per sphere, > 0 = index of refraction
     unsigned long long *counters; // [path, shadow] or nullptr
     unsigned int *queue;  // work-queue head for the persistent kernel
+    unsigned ring_at;     // render_rounds_kernel<.., .., true>: where the waves' shading rings start in LDS, in doubles
     int width, height;
     int tile_rows, tile_first, tile_step;
     int local_rows;
     int bounce_limit, spp;
 };
+
+// the same with the division as a multiply-high (f.tile_magic = min(ceil(2^32 / tile_rows), 2^32 - 1): off by at most one)
+TRT_DEV int frame_row_of_magic(const FrameView &f, unsigned local_row)
+{
+    unsigned t = __umulhi(local_row, f.tile_magic);
+    int within = (int)(local_row - t * (unsigned)f.tile_rows);
+    if (within < 0)
+        t--, within += f.tile_rows;
+    else if (within >= f.tile_rows)
+        t++, within -= f.tile_rows;
+    return (f.tile_first + (int)t * f.tile_step) * f.tile_rows + within;
+}
 
 TRT_DEV int frame_row_of(const FrameView &f, int local_row)
 {
@@ -307,7 +322,7 @@ TRT_DEV uint32_t sky_texel(const uint32_t *sky, int dim, d3 direction)
 // resulting zeros is exact, so t_f = +-component, scale_by = the winning t, and u, v are +-0.5 * a
 // component of dir*(1/scale_by).  Only the sign of a zero can differ from the table form, and no
 // later step (clamp, +0.5, *dim, truncation) can see it.  Assumes finite components.
-TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir)
+TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir, double dim_f)
 {
     const double t[6] = {dir.x, -dir.x, dir.y, -dir.y, dir.z, -dir.z};
     int face = 0;
@@ -348,12 +363,17 @@ TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir)
     }
     u = clampd(u, -0.5, 0.5);
     v = clampd(v, -0.5, 0.5);
-    const int ui = d2i((u + 0.5) * dim);
-    const int vi = d2i((v + 0.5) * dim);
+    const int ui = d2i((u + 0.5) * dim_f);
+    const int vi = d2i((v + 0.5) * dim_f);
     long idx = (long)ui + (long)vi * dim;
     const long last = (long)dim * dim - 1;
     idx = idx > last ? last : (idx < 0 ? 0 : idx);
     return sky[(long)face * dim * dim + idx];
+}
+
+TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir)
+{
+    return sky_texel_unit(sky, dim, dir, (double)dim);
 }
 
 TRT_DEV d3 texel_color(uint32_t t) // TRT.c:866: byte / 255.0

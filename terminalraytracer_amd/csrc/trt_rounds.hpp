@@ -423,19 +423,20 @@ TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n
     const double *rec = L.fam + 4 * i;
     d3 apex = mirrored ? load3(rec) : load3(L.sph + 4 * i);
     double r_chk = mirrored ? rec[3] + TRT_FAMILY_SLACK : rec[3];
-    double rg2 = G.rg2_sph;
+    const double *E = L.eye + TRT_RAYFAMILY_DOUBLES * (f & 1);
+    const double rg2_eye = E[5];
     if (of_eye)
     {
-        const double *E = L.eye + TRT_RAYFAMILY_DOUBLES * (f & 1);
         apex = load3(E);
         r_chk = E[3];
-        rg2 = E[5];
     }
-    // trt_rayfamily_member, operation for operation
+    const double rg2 = of_eye ? rg2_eye : G.rg2_sph; // by value: a pointer chosen between LDS and the kernel arguments is a flat load
+    // trt_rayfamily_member, operation for operation (all four conditions evaluated: no branches between them)
     const d3 w = sub(o, apex);
     const d3 c = d3{w.y * d.z - w.z * d.y, w.z * d.x - w.x * d.z, w.x * d.y - w.y * d.x};
-    const bool member = dot(c, c) <= r_chk * r_chk && dot(w, d) >= -r_chk && dot(w, w) <= rg2 &&
-                        __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
+    const bool near_line = dot(c, c) <= r_chk * r_chk, ahead = dot(w, d) >= -r_chk, in_range = dot(w, w) <= rg2;
+    const bool unit_dir = __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
+    const bool member = near_line & ahead & in_range & unit_dir;
     const int g = of_eye ? G.g_eye : G.g_sph;
     const int at = trt_cubemap_cell((float)d.x, (float)d.y, (float)d.z, 0.5f * (float)g, (float)(g - 1), g);
     const unsigned eye_cells = 6u * (unsigned)G.g_eye * (unsigned)G.g_eye, sph_cells = 6u * (unsigned)G.g_sph * (unsigned)G.g_sph;
@@ -447,10 +448,16 @@ TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n
     return cell;
 }
 
+// how many lanes below this one are set in `mask` (v_mbcnt: no lane mask to keep in registers)
+TRT_DEV unsigned lanes_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
 // Per-lane counters of the counting kernel variant and the stamps of the diagnostic build, handed through the stages.
 struct Tally
 {
-    unsigned path = 0, shadow = 0, rounds = 0, phase2 = 0, swept = 0;
+    unsigned path = 0, shadow = 0, rounds = 0, phase2 = 0, swept = 0, passes = 0;
 #if TRT_STAMP
     unsigned long long stamp_sum[24] = {0}, stamp_prev = 0;
 #endif
@@ -640,9 +647,23 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
 // the surface; inside, that sphere is met at its far root; leaving it adds no colour and no weight but costs a bounce; total
 // internal reflection mirrors the ray.  Restated operation for operation in oracle/trt_oracle.c (shade_pixel_refractive).
 // The default instantiation (REFRACT = false) is the reference's path, unchanged.
-template <bool COUNT, bool REFRACT = false>
-__global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
+//
+// COMPACT: the shading of a hit (the shadow rays of S and the clamp, TRT.c:894-962) is decoupled from the lane that owns the
+// sample.  A hit becomes a TASK {nudged point, normal, material, weight} in a ring in LDS that belongs to the wave; the wave
+// shades tasks 64 at a time, whichever lanes they came from, and a task may wait for the NEXT round's hits to fill the pass
+// it runs in -- never longer, so that a lane has at most two colours outstanding and they reach its sample in bounce order
+// (TRT.c:1040 adds them in that order; the sky colour of TRT.c:1044 after them).  What is computed for a task is what the
+// owner would have computed, operation for operation; only WHICH lane computes it, and when, changes.
+constexpr int kRingTasks = 128;                            // >= 63 carried over + 64 new
+constexpr int kRingDoubles = 7 * kRingTasks + kRingTasks / 2 + 3 * 64; // point(3) normal(3) weight(1) as arrays of doubles, material as ints;
+                                                                        // then per LANE the direction of its next path ray while the wave shades
+
+constexpr int kCompactBlock = 1024; // one workgroup per CU: 16 rings and one image share the CU's 160 KB of LDS
+
+template <bool COUNT, bool REFRACT = false, bool COMPACT = false>
+__global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPACT && !COUNT) ? 4 : TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
 {
+    static_assert(!(REFRACT && COMPACT), "the refraction extension runs on the plain rounds");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const LdsImage L = stage_lds_image(lds, s, cull, f, grids);
     const int n = s.num_spheres, nd = s.num_dir, nl = s.num_dir + s.num_point;
@@ -664,6 +685,19 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
     int inside = -1;                                  // REFRACT: the refractor the pending ray travels inside of
     Tally tally;
     unsigned pool_next = 0, pool_end = 0; // wave-uniform: units fetched from the queue, not yet handed out
+    // COMPACT: the wave's ring of shading tasks and what this lane still expects from it
+    double *const ring = lds + f.ring_at + (threadIdx.x >> 6) * kRingDoubles;
+    int *const ring_mat = (int *)(ring + 7 * kRingTasks);
+    double *const parked = ring + 7 * kRingTasks + kRingTasks / 2;
+    if (COMPACT)
+    {
+        for (int i = lane; i < kRingDoubles; i += 64)
+            ring[i] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    unsigned q_head = 0, q_tail = 0, q_old = 0; // wave-uniform counters: [q_head, q_tail) waits, tasks below q_old are of the previous round
+    unsigned my_task = 0, old_task = 0;         // this round's task of the lane, the previous round's
+    bool my_open = false, old_open = false;     // ... whose colour has not arrived yet
 
     TRT_STAGE_STAMPS(tally);
 #if TRT_STAMP
@@ -678,7 +712,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             if (need)
             {
                 const unsigned wanted = (unsigned)__builtin_popcountll(need);
-                const unsigned rank = (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+                const unsigned rank = lanes_below(need);
                 unsigned mine = pool_next + rank;
                 if (pool_end - pool_next < wanted)
                 { // refill the wave's pool with ONE atomic; what is left of the old chunk is served first
@@ -715,7 +749,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                         else if (col >= f.width)
                             row++, col -= f.width;
                         const double sx = f.col_x[col] + L.jit[k];
-                        const double sy = f.row_y[frame_row_of(f, (int)row)] + L.jit[f.spp + k];
+                        const double sy = f.row_y[frame_row_of_magic(f, row)] + L.jit[f.spp + k];
                         d3 dir = d3{0.0, 0.0, 0.0};
                         dir = add(dir, scale(load3(L.cam + 0), sx));
                         dir = add(dir, scale(load3(L.cam + 3), sy));
@@ -745,6 +779,104 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             tally.path++;
         TRT_STAMP_AT(1); // unit(next_dir)
         const PathHit hit = path_stage<COUNT, REFRACT>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside);
+        if constexpr (COMPACT)
+        {
+            const bool path_hit = hit.hit, path_sky = hit.sky;
+            bool end_sample = path_sky;
+            uint32_t sky_t = 0;
+            if (path_sky)
+                sky_t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f); // TRT.c:858-867; added to the sample after the colours still on their way
+            // ---- a hit becomes a task; what does not depend on its colour happens now (TRT.c:1036-1038, :1054) ----
+            const unsigned long long hits = __ballot(path_hit);
+            const double weight_before = weight;
+            if (hits)
+            {
+                if (path_hit)
+                {
+                    my_task = q_tail + lanes_below(hits);
+                    my_open = true;
+                    const unsigned at = my_task & (kRingTasks - 1);
+                    const d3 so = add(hit.ph.p, scale(hit.back, 0.000001)); // TRT.c:873-874
+                    ring[0 * kRingTasks + at] = so.x, ring[1 * kRingTasks + at] = so.y, ring[2 * kRingTasks + at] = so.z;
+                    ring[3 * kRingTasks + at] = hit.normal.x, ring[4 * kRingTasks + at] = hit.normal.y, ring[5 * kRingTasks + at] = hit.normal.z;
+                    ring[6 * kRingTasks + at] = weight;
+                    ring_mat[at] = hit.mat;
+                    const d3 nd3 = reflect(d, hit.normal); // TRT.c:1054; kept in LDS while the wave shades
+                    parked[lane] = nd3.x, parked[64 + lane] = nd3.y, parked[128 + lane] = nd3.z;
+                    weight *= L.mat[hit.mat * 5 + 3];
+                    bounces++;
+                    end_sample = !(bounces < f.bounce_limit && weight > 0.00001); // TRT.c:1018
+                }
+                q_tail += (unsigned)__builtin_popcountll(hits);
+            }
+            if (alive)
+                weight_sum += weight_before; // TRT.c:1034 (a sample that ends is normalised by this sum, one that goes on carries it)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the ring is written by some lanes and read by others
+            TRT_STAMP_AT(7); // P post: sky texel, reflection, nudge, enqueue
+            // ---- S over tasks: every task of the previous round, then whole passes; everything if a sample ends on its hit ----
+            const bool flush = __any(end_sample && path_hit);
+            while (q_head != q_tail && ((int)(q_old - q_head) > 0 || q_tail - q_head >= 64u || flush))
+            {
+                const unsigned take = q_tail - q_head < 64u ? q_tail - q_head : 64u;
+                const bool has = (unsigned)lane < take;
+                const unsigned at = (q_head + (unsigned)lane) & (kRingTasks - 1);
+                // lanes beyond `take` read whatever their slot holds -- an old task or the zeros the ring started with -- and
+                // take no part in the stage (lit_lanes = has); nothing they compute is stored
+                const d3 so = d3{ring[0 * kRingTasks + at], ring[1 * kRingTasks + at], ring[2 * kRingTasks + at]};
+                const d3 sn = d3{ring[3 * kRingTasks + at], ring[4 * kRingTasks + at], ring[5 * kRingTasks + at]};
+                const int sm = ring_mat[at];
+                if (COUNT)
+                    tally.passes++;
+                const d3 lit = shadow_stage<COUNT>(L, cull, grids, n, nd, nl, so, sn, sm, has, gp, gn, tally);
+                d3 color = d3{clampd(lit.x, 0.0, 1.0), clampd(lit.y, 0.0, 1.0), clampd(lit.z, 0.0, 1.0)}; // TRT.c:960-962
+                color = scale(color, ring[6 * kRingTasks + at]);                                          // TRT.c:1035
+                if (has) // the colour takes the place of the normal in the task's record; its owner collects it at the END of a round
+                    ring[3 * kRingTasks + at] = color.x, ring[4 * kRingTasks + at] = color.y, ring[5 * kRingTasks + at] = color.z;
+                q_head += take;
+            }
+            q_old = q_tail;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            TRT_STAMP_AT(20); // lit accumulate
+            // ---- colours that have arrived, in bounce order (TRT.c:1040): last round's task is shaded by now, this round's may be ----
+            if (old_open)
+            {
+                const unsigned at = old_task & (kRingTasks - 1);
+                sample = add(sample, d3{ring[3 * kRingTasks + at], ring[4 * kRingTasks + at], ring[5 * kRingTasks + at]});
+            }
+            if (my_open && (int)(q_head - my_task) > 0)
+            {
+                const unsigned at = my_task & (kRingTasks - 1);
+                sample = add(sample, d3{ring[3 * kRingTasks + at], ring[4 * kRingTasks + at], ring[5 * kRingTasks + at]});
+                my_open = false;
+            }
+            // ======================================= END of the bounce =======================================
+            if (path_hit)
+            { // the next path ray: from the nudged point, along the reflection
+                o = d3{ring[0 * kRingTasks + (my_task & (kRingTasks - 1))], ring[1 * kRingTasks + (my_task & (kRingTasks - 1))],
+                       ring[2 * kRingTasks + (my_task & (kRingTasks - 1))]};
+                next_dir = d3{parked[lane], parked[64 + lane], parked[128 + lane]};
+            }
+            old_task = my_task, old_open = my_open, my_open = false;
+            if (path_sky)
+            { // TRT.c:1044-1048: colour = texel, the sample ends here
+                const d3 color = d3{L.b255[sky_t & 0xFF], L.b255[(sky_t >> 8) & 0xFF], L.b255[(sky_t >> 16) & 0xFF]};
+                sample = add(sample, scale(color, weight));
+            }
+            if (__any(end_sample))
+            { // TRT.c:1061
+                const double q = 1.0 / weight_sum;
+                if (end_sample)
+                {
+                    double *out = f.samples + (size_t)slot_id * 3;
+                    out[0] = sample.x * q;
+                    out[1] = sample.y * q;
+                    out[2] = sample.z * q;
+                    want_unit = true;
+                }
+            }
+        }
+        else
+        {
         // REFRACT: the ray leaves the refractor it was inside of -- no shading, no weight, one bounce
         const bool leaving = REFRACT && hit.hit && hit.ph.i == inside;
         const bool path_hit = hit.hit && !leaving, path_sky = hit.sky;
@@ -754,7 +886,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
         double weight_sum_new = weight_sum + weight; // TRT.c:1034
         if (path_sky)
         { // TRT.c:858-867, :1044-1048: colour = texel, the sample ends here
-            const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, hit.back);
+            const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f);
             const d3 color = d3{L.b255[t & 0xFF], L.b255[(t >> 8) & 0xFF], L.b255[(t >> 16) & 0xFF]};
             sample = add(sample, scale(color, weight));
             end_sample = true;
@@ -769,6 +901,8 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             }
             TRT_STAMP_AT(7); // P post: sky texel, reflection, nudge
             // ===================================== S(i): shadow rays =====================================
+            if (COUNT && __any(path_hit))
+                tally.passes++;
             lit = shadow_stage<COUNT>(L, cull, grids, n, nd, nl, o, h_normal, h_mat, path_hit, gp, gn, tally);
         }
         else
@@ -843,6 +977,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
                 want_unit = true;
             }
         }
+        }
         TRT_STAMP_AT(21); // END of the bounce
     }
 
@@ -855,6 +990,7 @@ __global__ __launch_bounds__(kPersistentBlock, TRT_ROUNDS_WAVES) void render_rou
             atomicAdd(&f.counters[2], (unsigned long long)tally.rounds);
             atomicAdd(&f.counters[3], (unsigned long long)tally.phase2);
             atomicAdd(&f.counters[28], (unsigned long long)tally.swept); // traces in which the wave fell back to the sweep
+            atomicAdd(&f.counters[29], (unsigned long long)tally.passes); // times the wave ran the shadow stage
 #if TRT_STAMP
             for (int i = 0; i < 24; i++)
                 atomicAdd(&f.counters[4 + i], stamp_sum[i]);
@@ -897,7 +1033,7 @@ __global__ __launch_bounds__(kPersistentBlock) void probe_rounds_kernel(SceneVie
     }
     else
     {
-        const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, hit.back);
+        const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f);
         color = d3{L.b255[t & 0xFF], L.b255[(t >> 8) & 0xFF], L.b255[(t >> 16) & 0xFF]};
     }
     obj[i] = hit.hit ? (hit.ph.i < n ? 1 : 2) : 0;

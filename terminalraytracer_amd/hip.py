@@ -70,8 +70,10 @@ SYMBOLS = {
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
     "trt_set_path_grids": (_I, [_VP, _I, _I]),
     "trt_set_path_grids_min_spheres": (_I, [_VP, _I]),
+    "trt_set_compaction": (_I, [_VP, _I]),
     "trt_read_path_tables": (C.c_long, [_VP, C.POINTER(L.Camera), _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_long)]),
     "trt_read_sweep_fallbacks": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
+    "trt_read_shading_passes": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
     "trt_set_refraction": (_I, [_VP, _VP, _I]),
     "trt_reserve_cus": (_I, [_VP, _I]),
     "trt_get_stream": (_I, [_VP, C.POINTER(C.c_void_p)]),
@@ -192,6 +194,10 @@ class Context:
         """scenes with fewer spheres keep the sweep for their path rays (trt_set_path_grids_min_spheres)"""
         _check(lib().trt_set_path_grids_min_spheres(self._h, min_spheres))
 
+    def set_compaction(self, mode):
+        """shading decoupled from the owning lane: -1 when it costs no occupancy (default), 0 never, 1 whenever it fits (trt_set_compaction)"""
+        _check(lib().trt_set_compaction(self._h, mode))
+
     def read_path_tables(self, camera_array):
         """(info dict, list cells uint64[], pool uint64[]) of the path rays' tables as built for this camera's eye"""
         cam = camera_struct(camera_array)
@@ -279,7 +285,9 @@ class Context:
     def read_diagnostics(self):
         t, p = C.c_ulonglong(), C.c_ulonglong()
         _check(lib().trt_read_diagnostics(self._h, C.byref(t), C.byref(p)))
-        return {"wave_loop_trips": t.value, "phase2_rounds": p.value, "swept_traces": self.read_sweep_fallbacks()}
+        v = C.c_ulonglong()
+        _check(lib().trt_read_shading_passes(self._h, C.byref(v)))
+        return {"wave_loop_trips": t.value, "phase2_rounds": p.value, "swept_traces": self.read_sweep_fallbacks(), "shading_passes": v.value}
 
     def kernel_info(self):
         v = [_I() for _ in range(5)]

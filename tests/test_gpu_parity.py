@@ -16,9 +16,12 @@ pytestmark = pytest.mark.gpu
 
 SMALL = T.golden_cases(("small", "medium"))
 LARGE = T.golden_cases(("large",))
-# the production kernel and the reference-order kernel: two independent HIP implementations of the path
-KERNELS = [hip.Context.PRODUCTION, hip.Context.REFERENCE_ORDER]
-KERNEL_IDS = ["production_rounds", "reference_order"]
+# the production kernel as it ships (the shading decoupled from the owning lane for scenes of three lights or more,
+# trt_set_compaction(-1)), the same with the decoupling forced on, and the reference-order kernel -- an independent HIP
+# implementation of the path
+COMPACT = "production_rounds_compact"
+KERNELS = [hip.Context.PRODUCTION, COMPACT, hip.Context.REFERENCE_ORDER]
+KERNEL_IDS = ["production_rounds", COMPACT, "reference_order"]
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +37,8 @@ def bits(a):
 
 
 def render(ctx, scene, w, h, b, s, kernel=hip.Context.PRODUCTION, rows=None):
-    ctx.set_kernel(kernel)
+    ctx.set_kernel(hip.Context.PRODUCTION if kernel == COMPACT else kernel)
+    ctx.set_compaction(1 if kernel == COMPACT else -1)
     ctx.set_scene(scene)
     return ctx.render_host(scene.camera, rows or hip.RowSet.whole(w, h), b, s)
 
@@ -834,3 +838,72 @@ def test_drop_in_symbol_may_be_called_from_several_threads(tmp_path):
                            "-L" + libdir, "-ltrt_hip", "-Wl,-rpath," + libdir, "-lpthread"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "identical" in out.stdout, out.stdout + out.stderr
+
+
+def _shadow_lane_activity(ctx, scene, w, h, b, spp, kernel):
+    ctx.enable_counters(True)
+    try:
+        frame = render(ctx, scene, w, h, b, spp, kernel)
+        path, shadow = ctx.read_counters()
+        passes = ctx.read_diagnostics()["shading_passes"]
+    finally:
+        ctx.enable_counters(False)
+    hits = shadow / (len(scene.dir_lights) + len(scene.point_lights))
+    return frame, hits / (64.0 * passes)
+
+
+def test_compaction_fills_the_shadow_lanes_of_the_bench_frame(ctx):
+    """BASELINE config 3 at full size with the shading decoupled from the owning lane: the frame is the one the genuine
+    reference produced (FNV of tests/golden/golden_full.json), and the shadow stage runs with more than 90 % of its lanes
+    busy (61 % without: the share of path rays that hit something)."""
+    case = T.golden_full()["c3_1080p_64sph_b8"]
+    w, h, b, spp = case["width"], case["height"], case["bounce_limit"], case["rays_per_pixel"]
+    scene = T.full_scene(case)
+    plain, idle = _shadow_lane_activity(ctx, scene, w, h, b, spp, hip.Context.PRODUCTION)  # two lights: the default leaves it off
+    packed, busy = _shadow_lane_activity(ctx, scene, w, h, b, spp, COMPACT)
+    assert T.fnv(plain) == case["fb_fnv"] and T.fnv(packed) == case["fb_fnv"]
+    assert idle < 0.7 and busy > 0.9, (idle, busy)
+
+
+def test_compaction_is_the_default_from_three_lights_up(ctx):
+    """trt_set_compaction(-1): off for the two lights of the BASELINE scenes, on when a third light makes it pay; the frame
+    equals the oracle's either way, and the reference-order kernel's."""
+    w, h = 480, 270
+    base = S.synth_scene(64, T.sky("synth"), T.bench_camera(w, h, 2.5), seed=7)
+    rng = np.random.default_rng(11)
+    extra = np.concatenate([rng.normal(size=(3, 3)) * 4 + [0, 4, 0], rng.uniform(0.1, 0.5, (3, 3)), rng.uniform(5, 30, (3, 1))], axis=1)
+    many = S.SceneData(base.spheres, base.ground, base.dir_lights, np.concatenate([base.point_lights, extra]), base.camera, base.sky)
+    _, two = _shadow_lane_activity(ctx, base, w, h, 8, 10, hip.Context.PRODUCTION)
+    frame, five = _shadow_lane_activity(ctx, many, w, h, 8, 10, hip.Context.PRODUCTION)
+    assert two < 0.75 < 0.85 < five, (two, five)
+    want, _ = T.oracle_render(many, w, h, 8, 10)
+    assert np.array_equal(bits(frame), bits(want))
+    assert np.array_equal(bits(render(ctx, many, w, h, 8, 10, hip.Context.REFERENCE_ORDER)), bits(want))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_compaction_on_fuzzed_scenes_with_many_lights(ctx, seed):
+    """The decoupled shading against the oracle where its bookkeeping is busiest: up to six lights of each kind, bounce
+    limits from 1 (every hit ends its sample: the ring is flushed every round) to 12, 1 / 3 / 10 rays per pixel, frames
+    narrower than a wave, scenes without spheres."""
+    rng = np.random.default_rng(7000 + seed)
+    w, h = int(rng.integers(8, 96)), int(rng.integers(4, 54))
+    b, spp = int(rng.choice([1, 1, 2, 3, 8, 12])), int(rng.choice([1, 3, 10]))
+    scene = _fuzz_scene(rng, w, h)
+    nd, npt = int(rng.integers(0, 7)), int(rng.integers(0, 7))
+    dl = np.concatenate([rng.normal(size=(nd, 3)) - [0, 1.0, 0], rng.uniform(0, 0.6, (nd, 3))], axis=1)
+    pl = np.concatenate([rng.normal(size=(npt, 3)) * 10.0 ** rng.uniform(-1, 1.5, (npt, 1)), rng.uniform(0, 0.6, (npt, 3)),
+                         rng.uniform(0.0, 50.0, (npt, 1))], axis=1)
+    scene = S.SceneData(scene.spheres, scene.ground, dl.reshape(-1, 6), pl.reshape(-1, 7), scene.camera, scene.sky)
+    with np.errstate(all="ignore"):
+        want, st = T.oracle_render(scene, w, h, b, spp)
+    ctx.enable_counters(True)
+    try:
+        got = render(ctx, scene, w, h, b, spp, COMPACT)
+        counts = ctx.read_counters()
+    finally:
+        ctx.enable_counters(False)
+    finite = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(bits(got[finite]), bits(want[finite]))
+    assert counts == (st.path_rays, st.shadow_rays)
+    assert np.array_equal(bits(render(ctx, scene, w, h, b, spp, COMPACT)), bits(got))  # and without the counting variant
