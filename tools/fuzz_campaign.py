@@ -54,14 +54,17 @@ def light_heavy_scene(rng, w, h):
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
-make = {"wide": wide_scene, "lights": light_heavy_scene}.get(mode, P._fuzz_scene)
+make = {"wide": wide_scene, "lights": light_heavy_scene, "compact": light_heavy_scene}.get(mode, P._fuzz_scene)
 refract = mode == "refract"  # EXTENSION, parity unpinned: against the oracle's restatement of the extension, not the reference
 bad = 0
 with hip.Context(0) as ctx:
+    kernel = P.COMPACT if mode == "compact" else hip.Context.PRODUCTION  # "compact": the decoupled shading (trt_set_compaction) forced on
     for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
         w, h = int(rng.integers(8, 160)), int(rng.integers(4, 90))
         b, spp = int(rng.integers(1, 13)), int(rng.choice([1, 3, 10]))
+        if mode == "compact" and seed % 3 == 0:
+            b = 1  # every hit ends its sample: the ring is flushed in every round
         scene = make(rng, w, h)
         ior = None
         if refract and len(scene.spheres):
@@ -72,7 +75,7 @@ with hip.Context(0) as ctx:
                 want, st = T.oracle_render_refractive(scene, ior, w, h, b, spp)
             else:
                 want, st = T.oracle_render(scene, w, h, b, spp)
-        got = P.render(ctx, scene, w, h, b, spp)
+        got = P.render(ctx, scene, w, h, b, spp, kernel)
         finite = np.isfinite(want)
         ok = np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(P.bits(got[finite]), P.bits(want[finite]))
         if not ok:
