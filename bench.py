@@ -314,6 +314,8 @@ def main():
         achieved = alg / (render_ms_avg * 1e-3) / 1e9
         path_mean = float(np.mean(path_cam))
         prof = committed_profile() if (world == 1 and workload == "c3") else None
+        variant = ctx0.render_variant()  # the shading decoupled from the owning lane or the plain rounds
+        variant_name = "render_rounds_kernel<false, false, %s>" % ("true" if variant["decoupled"] else "false")
         out = {
             "metric": "path rays/s (primary+secondary) at 1920x1080, 64 spheres, 8 bounces" if workload == "c3" else
                       "path rays/s (primary+secondary) at 1920x1080, 256 spheres, 12 bounces, orbiting camera",
@@ -324,7 +326,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["text"] if args.sky_dim == SKY_DIM else wl["text"].replace("256^2", f"{args.sky_dim}^2"), "sharding": f"{world} x interleaved {args.tile_rows}-row tiles, 1 gather/frame",
                        "multi_gpu_path": "PyTorch-level rehearsal (gloo)" if rehearsal else "C-ABI trt_dist_* (RCCL send/recv gather inside the library)",
-                       "kernel": {0: "persistent waves, synchronous rounds", 1: "reference-order"}[args.kernel],
+                       "kernel": {0: "persistent waves, synchronous rounds" + (", shading decoupled from the owning lane" if variant["decoupled"] else ""),
+                                  1: "reference-order"}[args.kernel],
+                       "workgroup_threads": variant["workgroup_threads"],
                        "frames_in_flight": args.depth, "reserved_cus": args.reserve_cus},
             "frames_per_s": args.steps / seconds,
             "rays_per_frame": {"path": path_mean, "shadow": float(np.mean(shadow_cam))},
@@ -337,7 +341,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (prof or {}).get("hbm_bytes_per_launch"),
                          "traffic_source": (prof or {}).get("source"),
-                         "algorithmic_bytes": alg, "kernel": "render_rounds_kernel<false, false>", "kernel_ms": render_ms_avg,
+                         "algorithmic_bytes": alg, "kernel": variant_name, "kernel_ms": render_ms_avg,
                          "achieved_by_step": alg / (ms_step * 1e-3) / 1e9,
                          "note": "achieved = algorithmic bytes of a frame (SURVEY 8d) / the render kernel's own average duration, HIP events "
                                  "on its stream, frames launched strictly one at a time (one_frame_at_a_time); the timed region keeps "
@@ -348,7 +352,7 @@ def main():
             "kernel_info": ctx0.kernel_info(),
             # one round = one path ray per lane (+ one shadow ray per light for the lanes that hit something)
             "diagnostics": dict(diag, path_lane_utilisation=path_per_cam[0] / max(1, 64 * diag["wave_loop_trips"]),
-                                shadow_lane_utilisation=shadow_per_cam[0] / max(1, 64 * diag["wave_loop_trips"] * max(1, nd + npt)),
+                                shadow_lane_utilisation=shadow_per_cam[0] / max(1, 64 * diag["shading_passes"] * max(1, nd + npt)),
                                 exact_test_rounds_per_trace=diag["phase2_rounds"] / max(1, path_per_cam[0] + shadow_per_cam[0]) * 64)
             if args.kernel == 0 else diag,
         }

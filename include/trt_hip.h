@@ -160,11 +160,13 @@ int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres);
 
 /* Shading decoupled from the lane that owns the sample (render_rounds_kernel<.., .., true>): the hits of a
  * wave become tasks in a ring in LDS and are shaded 64 at a time, whichever lanes they came from, so that the shadow rays run
- * with ~95 % of the lanes busy instead of ~61 % (the share of path rays that hit something).  The ring costs about what one
- * light's idle lanes cost: mode -1 (default) uses it for scenes with three lights or more, when the rings fit in LDS beside
- * the scene without costing a resident wave; 0: never; 1: whenever the rings fit.  Frames are bit-identical in every mode.
- * Environment TRT_COMPACTION=-1|0|1 sets the default of new contexts. */
+ * with ~96 % of the lanes busy instead of ~61 % (the share of path rays that hit something).  The ring costs about what one
+ * light's idle lanes cost: mode -1 (default) uses it for scenes with two lights or more, when the rings fit in LDS beside
+ * the scene without costing a resident wave (up to ~100 spheres); 0: never; 1: whenever the rings fit.  Frames are
+ * bit-identical in every mode.  Environment TRT_COMPACTION=-1|0|1 sets the default of new contexts. */
 int trt_set_compaction(trt_context *ctx, int mode);
+/* Which form the next frame of the current scene runs: *decoupled 1 / 0, and the threads of a workgroup (1024 / 256). */
+int trt_render_variant(trt_context *ctx, int *decoupled, int *workgroup_threads);
 
 /* Copy the path rays' tables to the host (tests: the device-built lists must equal the host reference builder's): list
  * cells (2*6*eye_cells^2, then 2N*6*sphere_cells^2) and the pool of long lists, as built for `camera`'s eye.
@@ -197,7 +199,8 @@ int trt_read_shading_passes(trt_context *ctx, unsigned long long *passes);
  * (cells * ceil(N/64)), 0 when the tables are off, or a negative TRT_ERR_*. */
 long trt_read_light_grid(trt_context *ctx, int point_light, int index, unsigned long long *masks, size_t capacity_words);
 
-/* Resource usage of the selected render kernel (hipFuncGetAttributes / occupancy query). */
+/* Resource usage of the render kernel the next frame runs (hipFuncGetAttributes / occupancy query; max_blocks_per_cu counts
+ * workgroups of trt_render_variant's size). */
 int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *static_lds_bytes, int *max_blocks_per_cu,
                     int *compute_units);
 

@@ -179,7 +179,7 @@ struct trt_context
 namespace
 {
 
-constexpr int kCompactionMinLights = 3; // trt_set_compaction(-1): decouple the shading from three lights up
+constexpr int kCompactionMinLights = 2; // trt_set_compaction(-1): decouple the shading from two lights up (with one it is a wash)
 
 // LDS of render_rounds_kernel<.., false, true>: the image, then one shading ring per wave of the workgroup
 size_t compact_ring_at(const trt::SceneView &s, int spp)
@@ -190,6 +190,18 @@ size_t compact_ring_at(const trt::SceneView &s, int spp)
 size_t compact_lds_bytes(const trt::SceneView &s, int spp)
 {
     return sizeof(double) * (compact_ring_at(s, spp) + (size_t)(trt::kCompactBlock / 64) * trt::kRingDoubles);
+}
+
+// Does the next frame of this context run the kernel with the shading decoupled from the owning lane (COMPACT, trt_rounds.hpp)?
+// Measured (profiles/r02/n_compaction.md): 6 % faster with the two lights of the BASELINE scenes, 10 / 12 / 15 / 17 % with
+// 3 / 4 / 6 / 8; the ring costs about what one light's idle lanes cost.
+static bool renders_decoupled(const trt_context *ctx)
+{
+    if (ctx->kernel != 0 || ctx->ior_count || ctx->compact_blocks_per_cu <= 0 || ctx->compaction == 0)
+        return false;
+    const bool pays = ctx->scene.num_dir + ctx->scene.num_point >= kCompactionMinLights &&
+                      ctx->compact_blocks_per_cu * trt::kCompactBlock >= ctx->rounds_blocks_per_cu * trt::kPersistentBlock;
+    return ctx->compaction > 0 || pays;
 }
 
 size_t scene_lds_bytes(const trt::SceneView &s)
@@ -897,6 +909,18 @@ extern "C" int trt_read_sweep_fallbacks(trt_context *ctx, unsigned long long *sw
     return TRT_OK;
 }
 
+extern "C" int trt_render_variant(trt_context *ctx, int *decoupled, int *workgroup_threads)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    const bool d = ctx->have_scene && renders_decoupled(ctx);
+    if (decoupled)
+        *decoupled = d ? 1 : 0;
+    if (workgroup_threads)
+        *workgroup_threads = ctx->kernel == 1 ? 256 : (d ? trt::kCompactBlock : trt::kPersistentBlock);
+    return TRT_OK;
+}
+
 extern "C" int trt_read_shading_passes(trt_context *ctx, unsigned long long *passes)
 {
     if (!ctx || !passes)
@@ -1153,11 +1177,7 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
         // shading decoupled from the owning lane (COMPACT, trt_rounds.hpp) when the rings fit in LDS: by default only if they
         // cost no resident wave and the scene has lights enough to pay for them.
-        // Measured (profiles/r02/n_compaction.md): the ring costs what one light's idle lanes cost, so it is a wash with two
-        // lights and 5 / 7 / 11 / 14 % faster with 3 / 4 / 6 / 8.
-        const bool pays = ctx->scene.num_dir + ctx->scene.num_point >= kCompactionMinLights &&
-                          ctx->compact_blocks_per_cu * trt::kCompactBlock >= ctx->rounds_blocks_per_cu * trt::kPersistentBlock;
-        const bool compact = !ctx->ior_count && ctx->compact_blocks_per_cu > 0 && (ctx->compaction > 0 || (ctx->compaction < 0 && pays));
+        const bool compact = renders_decoupled(ctx);
         trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0),
                                                                 ctx->rounds_blocks_per_cu, units);
         if (compact)
@@ -1402,7 +1422,10 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
     if (!ctx)
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel : (const void *)trt::render_rounds_kernel<false>;
+    const bool decoupled = ctx->have_scene && renders_decoupled(ctx);
+    const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel
+                     : decoupled      ? (const void *)trt::render_rounds_kernel<false, false, true>
+                                      : (const void *)trt::render_rounds_kernel<false>;
     hipFuncAttributes attr;
     HIP_TRY(hipFuncGetAttributes(&attr, fn));
     if (vgprs)
@@ -1417,6 +1440,8 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
         const size_t lds = ctx->have_scene ? (ctx->kernel == 1 ? scene_lds_bytes(ctx->scene) : trt::rounds_lds_bytes(ctx->scene, 64)) : 0;
         if (ctx->kernel == 1)
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_simple_kernel, 256, lds));
+        else if (decoupled)
+            blocks = ctx->compact_blocks_per_cu; // workgroups of kCompactBlock threads
         else
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock, lds));
         *max_blocks_per_cu = blocks;

@@ -658,10 +658,14 @@ constexpr int kRingTasks = 128;                            // >= 63 carried over
 constexpr int kRingDoubles = 7 * kRingTasks + kRingTasks / 2 + 3 * 64; // point(3) normal(3) weight(1) as arrays of doubles, material as ints;
                                                                         // then per LANE the direction of its next path ray while the wave shades
 
-constexpr int kCompactBlock = 1024; // one workgroup per CU: 16 rings and one image share the CU's 160 KB of LDS
+#ifdef TRT_NATURAL
+constexpr int kCompactBlock = 256;
+#else
+constexpr int kCompactBlock = 1024;
+#endif // one workgroup per CU: 16 rings and one image share the CU's 160 KB of LDS
 
 template <bool COUNT, bool REFRACT = false, bool COMPACT = false>
-__global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPACT && !COUNT) ? 4 : TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
+__global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPACT && !COUNT && kCompactBlock == 1024) ? 4 : TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
 {
     static_assert(!(REFRACT && COMPACT), "the refraction extension runs on the plain rounds");
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
     Tally tally;
     unsigned pool_next = 0, pool_end = 0; // wave-uniform: units fetched from the queue, not yet handed out
     // COMPACT: the wave's ring of shading tasks and what this lane still expects from it
-    double *const ring = lds + f.ring_at + (threadIdx.x >> 6) * kRingDoubles;
+    double *const ring = lds + f.ring_at + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kRingDoubles; // wave-uniform: a scalar
     int *const ring_mat = (int *)(ring + 7 * kRingTasks);
     double *const parked = ring + 7 * kRingTasks + kRingTasks / 2;
     if (COMPACT)
@@ -696,8 +700,9 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
     unsigned q_head = 0, q_tail = 0, q_old = 0; // wave-uniform counters: [q_head, q_tail) waits, tasks below q_old are of the previous round
-    unsigned my_task = 0, old_task = 0;         // this round's task of the lane, the previous round's
+    unsigned my_task = 0, old_slot = 0;         // this round's task of the lane (its number), the previous round's (its place in the ring)
     bool my_open = false, old_open = false;     // ... whose colour has not arrived yet
+    bool waiting = false;                       // the sample ended on a hit whose colour arrives in the next round: the lane sits that round out
 
     TRT_STAGE_STAMPS(tally);
 #if TRT_STAMP
@@ -721,7 +726,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
                     const int leader = __builtin_ctzll(need);
                     if (lane == leader)
                         fresh = atomicAdd(f.queue, kQueueChunkSamples);
-                    fresh = __shfl(fresh, leader);
+                    fresh = (unsigned)__builtin_amdgcn_readlane((int)fresh, leader); // the leader is wave-uniform: no cross-lane permute, no lane id
                     if (rank >= left)
                         mine = fresh + (rank - left);
                     pool_next = fresh + (wanted - left);
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
                 }
             }
         }
-        if (!__any(alive))
+        if (!__any(alive || (COMPACT && waiting)))
             break;
         if (COUNT)
             tally.rounds++;
@@ -813,9 +818,9 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
                 weight_sum += weight_before; // TRT.c:1034 (a sample that ends is normalised by this sum, one that goes on carries it)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the ring is written by some lanes and read by others
             TRT_STAMP_AT(7); // P post: sky texel, reflection, nudge, enqueue
-            // ---- S over tasks: every task of the previous round, then whole passes; everything if a sample ends on its hit ----
-            const bool flush = __any(end_sample && path_hit);
-            while (q_head != q_tail && ((int)(q_old - q_head) > 0 || q_tail - q_head >= 64u || flush))
+            // ---- S over tasks: ONE pass of up to 64 tasks from the head of the ring, if a task of the previous round waits (they
+            // are at the head, fewer than 64) or 64 wait.  At most 63 stay behind, so 63 + 64 is the most the ring ever holds. ----
+            if (q_head != q_tail && ((int)(q_old - q_head) > 0 || q_tail - q_head >= 64u))
             {
                 const unsigned take = q_tail - q_head < 64u ? q_tail - q_head : 64u;
                 const bool has = (unsigned)lane < take;
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
             // ---- colours that have arrived, in bounce order (TRT.c:1040): last round's task is shaded by now, this round's may be ----
             if (old_open)
             {
-                const unsigned at = old_task & (kRingTasks - 1);
+                const unsigned at = old_slot;
                 sample = add(sample, d3{ring[3 * kRingTasks + at], ring[4 * kRingTasks + at], ring[5 * kRingTasks + at]});
             }
             if (my_open && (int)(q_head - my_task) > 0)
@@ -856,18 +861,28 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
                        ring[2 * kRingTasks + (my_task & (kRingTasks - 1))]};
                 next_dir = d3{parked[lane], parked[64 + lane], parked[128 + lane]};
             }
-            old_task = my_task, old_open = my_open, my_open = false;
+            // A sample that ended on this round's hit while the hit's colour is still on its way waits for it: the lane sits
+            // the next round out (its task is then of the previous round: shaded whatever else happens) and stores the sample at
+            // that round's END.
+            bool finish = end_sample;
+            if (waiting)
+                finish = true, waiting = false; // the colour it waited for was added above
+            else if (end_sample && my_open)
+                finish = false, waiting = true, alive = false;
+            old_slot = my_task & (kRingTasks - 1), old_open = my_open, my_open = false;
             if (path_sky)
             { // TRT.c:1044-1048: colour = texel, the sample ends here
                 const d3 color = d3{L.b255[sky_t & 0xFF], L.b255[(sky_t >> 8) & 0xFF], L.b255[(sky_t >> 16) & 0xFF]};
                 sample = add(sample, scale(color, weight));
             }
-            if (__any(end_sample))
+            if (__any(finish))
             { // TRT.c:1061
                 const double q = 1.0 / weight_sum;
-                if (end_sample)
+                if (finish)
                 {
-                    double *out = f.samples + (size_t)slot_id * 3;
+                    unsigned slot = slot_id;
+                    asm volatile("" : "+v"(slot)); // the address is formed here, not kept as 64 bits for the life of the sample
+                    double *out = f.samples + (size_t)slot * 3;
                     out[0] = sample.x * q;
                     out[1] = sample.y * q;
                     out[2] = sample.z * q;

@@ -71,6 +71,7 @@ SYMBOLS = {
     "trt_set_path_grids": (_I, [_VP, _I, _I]),
     "trt_set_path_grids_min_spheres": (_I, [_VP, _I]),
     "trt_set_compaction": (_I, [_VP, _I]),
+    "trt_render_variant": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
     "trt_read_path_tables": (C.c_long, [_VP, C.POINTER(L.Camera), _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_long)]),
     "trt_read_sweep_fallbacks": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
     "trt_read_shading_passes": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
@@ -197,6 +198,12 @@ class Context:
     def set_compaction(self, mode):
         """shading decoupled from the owning lane: -1 when it costs no occupancy (default), 0 never, 1 whenever it fits (trt_set_compaction)"""
         _check(lib().trt_set_compaction(self._h, mode))
+
+    def render_variant(self):
+        """{"decoupled": bool, "workgroup_threads": int} of the kernel the next frame of the current scene runs (trt_render_variant)"""
+        d, t = _I(), _I()
+        _check(lib().trt_render_variant(self._h, C.byref(d), C.byref(t)))
+        return {"decoupled": bool(d.value), "workgroup_threads": t.value}
 
     def read_path_tables(self, camera_array):
         """(info dict, list cells uint64[], pool uint64[]) of the path rays' tables as built for this camera's eye"""

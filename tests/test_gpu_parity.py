@@ -20,6 +20,7 @@ LARGE = T.golden_cases(("large",))
 # trt_set_compaction(-1)), the same with the decoupling forced on, and the reference-order kernel -- an independent HIP
 # implementation of the path
 COMPACT = "production_rounds_compact"
+PLAIN = "production_rounds_plain"  # the decoupling forced off (what ships for scenes of one or two lights)
 KERNELS = [hip.Context.PRODUCTION, COMPACT, hip.Context.REFERENCE_ORDER]
 KERNEL_IDS = ["production_rounds", COMPACT, "reference_order"]
 
@@ -37,8 +38,8 @@ def bits(a):
 
 
 def render(ctx, scene, w, h, b, s, kernel=hip.Context.PRODUCTION, rows=None):
-    ctx.set_kernel(hip.Context.PRODUCTION if kernel == COMPACT else kernel)
-    ctx.set_compaction(1 if kernel == COMPACT else -1)
+    ctx.set_kernel(hip.Context.PRODUCTION if kernel in (COMPACT, PLAIN) else kernel)
+    ctx.set_compaction({COMPACT: 1, PLAIN: 0}.get(kernel, -1))
     ctx.set_scene(scene)
     return ctx.render_host(scene.camera, rows or hip.RowSet.whole(w, h), b, s)
 
@@ -853,32 +854,33 @@ def _shadow_lane_activity(ctx, scene, w, h, b, spp, kernel):
 
 
 def test_compaction_fills_the_shadow_lanes_of_the_bench_frame(ctx):
-    """BASELINE config 3 at full size with the shading decoupled from the owning lane: the frame is the one the genuine
-    reference produced (FNV of tests/golden/golden_full.json), and the shadow stage runs with more than 90 % of its lanes
-    busy (61 % without: the share of path rays that hit something)."""
+    """BASELINE config 3 at full size with the shading decoupled from the owning lane (what ships for it) and with the
+    decoupling forced off: both frames are the one the genuine reference produced (FNV of tests/golden/golden_full.json), and
+    the shadow stage runs with more than 90 % of its lanes busy (61 % without: the share of path rays that hit something)."""
     case = T.golden_full()["c3_1080p_64sph_b8"]
     w, h, b, spp = case["width"], case["height"], case["bounce_limit"], case["rays_per_pixel"]
     scene = T.full_scene(case)
-    plain, idle = _shadow_lane_activity(ctx, scene, w, h, b, spp, hip.Context.PRODUCTION)  # two lights: the default leaves it off
+    plain, idle = _shadow_lane_activity(ctx, scene, w, h, b, spp, PLAIN)
     packed, busy = _shadow_lane_activity(ctx, scene, w, h, b, spp, COMPACT)
-    assert T.fnv(plain) == case["fb_fnv"] and T.fnv(packed) == case["fb_fnv"]
-    assert idle < 0.7 and busy > 0.9, (idle, busy)
+    shipped, default = _shadow_lane_activity(ctx, scene, w, h, b, spp, hip.Context.PRODUCTION)
+    assert T.fnv(plain) == case["fb_fnv"] and T.fnv(packed) == case["fb_fnv"] and T.fnv(shipped) == case["fb_fnv"]
+    assert idle < 0.7 and busy > 0.9 and default > 0.9, (idle, busy, default)
 
 
-def test_compaction_is_the_default_from_three_lights_up(ctx):
-    """trt_set_compaction(-1): off for the two lights of the BASELINE scenes, on when a third light makes it pay; the frame
-    equals the oracle's either way, and the reference-order kernel's."""
+def test_compaction_default_policy(ctx):
+    """trt_set_compaction(-1): on from two lights up when the rings fit in LDS beside the scene, off for a single light (a wash)
+    and for a 256-sphere scene (no room: forcing it on changes nothing either); every frame equals the oracle's."""
     w, h = 480, 270
     base = S.synth_scene(64, T.sky("synth"), T.bench_camera(w, h, 2.5), seed=7)
-    rng = np.random.default_rng(11)
-    extra = np.concatenate([rng.normal(size=(3, 3)) * 4 + [0, 4, 0], rng.uniform(0.1, 0.5, (3, 3)), rng.uniform(5, 30, (3, 1))], axis=1)
-    many = S.SceneData(base.spheres, base.ground, base.dir_lights, np.concatenate([base.point_lights, extra]), base.camera, base.sky)
-    _, two = _shadow_lane_activity(ctx, base, w, h, 8, 10, hip.Context.PRODUCTION)
-    frame, five = _shadow_lane_activity(ctx, many, w, h, 8, 10, hip.Context.PRODUCTION)
-    assert two < 0.75 < 0.85 < five, (two, five)
-    want, _ = T.oracle_render(many, w, h, 8, 10)
-    assert np.array_equal(bits(frame), bits(want))
-    assert np.array_equal(bits(render(ctx, many, w, h, 8, 10, hip.Context.REFERENCE_ORDER)), bits(want))
+    one = S.SceneData(base.spheres, base.ground, base.dir_lights, base.point_lights[:0], base.camera, base.sky)
+    big = S.synth_scene(256, T.sky("synth"), T.bench_camera(w, h, 2.5), seed=7)
+    assert len(base.dir_lights) + len(base.point_lights) == 2 and len(one.dir_lights) == 1
+    for scene, kernel, decoupled in ((base, hip.Context.PRODUCTION, True), (one, hip.Context.PRODUCTION, False), (one, COMPACT, True),
+                                     (big, hip.Context.PRODUCTION, False), (big, COMPACT, False)):
+        frame, activity = _shadow_lane_activity(ctx, scene, w, h, 8, 10, kernel)
+        assert (activity > 0.85) == decoupled and (decoupled or activity < 0.8), (len(scene.spheres), kernel, activity)
+        want, _ = T.oracle_render(scene, w, h, 8, 10)
+        assert np.array_equal(bits(frame), bits(want))
 
 
 @pytest.mark.parametrize("seed", range(16))

@@ -9,9 +9,12 @@ import test_gpu_parity as P
 
 import torch
 
-def timed(ctx, scene, w, h, b, spp, reps=20):
+MODES = {0: P.PLAIN, 1: P.COMPACT}
+
+def timed(ctx, scene, w, h, b, spp, mode, reps=20):
     """median duration of the render kernel over whole frames rendered into device memory (no bands, no copies)"""
     ctx.set_scene(scene)
+    ctx.set_compaction(mode)
     buf = torch.empty(w * h * 3, dtype=torch.float64, device="cuda:0")
     rows = hip.RowSet.whole(w, h)
     ts = []
@@ -21,10 +24,10 @@ def timed(ctx, scene, w, h, b, spp, reps=20):
         ts.append(ctx.render_kernel_times()[0][-1])
     return float(np.median(ts[3:]))
 
-def stats(ctx, scene, w, h, b, spp):
+def stats(ctx, scene, w, h, b, spp, mode):
     ctx.enable_counters(True)
     try:
-        P.render(ctx, scene, w, h, b, spp)
+        P.render(ctx, scene, w, h, b, spp, MODES[mode])
         path, shadow = ctx.read_counters()
         d = ctx.read_diagnostics()
     finally:
@@ -45,8 +48,7 @@ with hip.Context(0) as ctx:
         with np.errstate(all="ignore"):
             want, st = T.oracle_render(scene, w, h, b, spp)
         for mode in (0, 1):
-            ctx.set_compaction(mode)
-            got = P.render(ctx, scene, w, h, b, spp)
+            got = P.render(ctx, scene, w, h, b, spp, MODES[mode])
             finite = np.isfinite(want)
             ok = np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(P.bits(got[finite]), P.bits(want[finite]))
             if not ok:
@@ -70,10 +72,9 @@ with hip.Context(0) as ctx:
                                 scene.camera, scene.sky)
         frames = {}
         for mode in (0, 1):
-            ctx.set_compaction(mode)
-            frames[mode] = P.render(ctx, scene, w, h, b, spp)
-            t = timed(ctx, scene, w, h, b, spp)
-            print(f"{name} compaction {mode}: render kernel {t:.4f} ms   {stats(ctx, scene, w, h, b, spp)}", flush=True)
+            frames[mode] = P.render(ctx, scene, w, h, b, spp, MODES[mode])
+            t = timed(ctx, scene, w, h, b, spp, mode)
+            print(f"{name} compaction {mode}: render kernel {t:.4f} ms   {stats(ctx, scene, w, h, b, spp, mode)}", flush=True)
         same = np.array_equal(P.bits(frames[0]), P.bits(frames[1]))
         print(f"{name}: on == off: {same}", flush=True)
         bad += 0 if same else 1

@@ -16,7 +16,7 @@ reduce_w, reduce_f = m(D, "WRITE_SIZE") * KB, m(D, "FETCH_SIZE") * KB
 total = render_w + 2 * render_f + reduce_w + 2 * reduce_f
 gui = m(R, "GRBM_GUI_ACTIVE") / 8.0
 out = {
-    "workload": "bench.py default (1920x1080, 64 spheres, 8 bounces, 10 rays/pixel), production kernels render_rounds_kernel<false, false> + reduce_samples_kernel, --depth 1",
+    "workload": "bench.py default (1920x1080, 64 spheres, 8 bounces, 10 rays/pixel), production kernels " + rk.replace("trt::", "") + " + reduce_samples_kernel, --depth 1",
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace; profiles/r02/{tag}_pmc_summary.txt (tools/profile_round.sh); means over the dispatches",
     "per_launch_KB": {"render_rounds_kernel": {"FETCH_SIZE": m(R, "FETCH_SIZE"), "WRITE_SIZE": m(R, "WRITE_SIZE")},
                       "reduce_samples_kernel": {"FETCH_SIZE": m(D, "FETCH_SIZE"), "WRITE_SIZE": m(D, "WRITE_SIZE")}},
@@ -31,7 +31,7 @@ out = {
             "the per-pixel mean is formed in the reference's order. It costs 0.10 ms (reduce kernel) of a 2.0 ms frame. The candidate tables (7 MB of list cells at 64 spheres) are "
             "read once per trace with 8-byte loads. The frame is bound by VALU issue and dependent-load latency, not by HBM.",
     "valu": {
-        "source": f"profiles/r02/{tag}_pmc_summary.txt (rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE), render_rounds_kernel<false, false>, means over the dispatches",
+        "source": f"profiles/r02/{tag}_pmc_summary.txt (rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE), " + rk.replace("trt::", "") + ", means over the dispatches",
         "SQ_INSTS_VALU_per_launch": m(R, "SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU": m(R, "SQ_ACTIVE_INST_VALU"), "SQ_WAVES": m(R, "SQ_WAVES"), "simds": 1024,
         "GRBM_GUI_ACTIVE_per_xcd": gui,
         "valu_busy_measured": 4.0 * m(R, "SQ_ACTIVE_INST_VALU") / (1024 * gui),
