@@ -31,6 +31,16 @@ constexpr int kPersistentBlock = TRT_BLOCK;
         stamp_sum[slot] += now_ - stamp_prev;                                                \
         stamp_prev = now_;                                                                   \
     } while (0)
+#elif defined(TRT_MARKS)
+// -DTRT_MARKS=1: the stage boundaries as comments in the compiler's assembly (tools/isa_stage_counts.py counts the
+// instructions between them); a scheduling barrier keeps each stage's instructions on its own side
+#define TRT_STAMP_AT(slot)                      \
+    do                                          \
+    {                                           \
+        __builtin_amdgcn_sched_barrier(0);      \
+        asm volatile("; MARK " #slot);          \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
 #else
 #define TRT_STAMP_AT(slot) \
     do                     \

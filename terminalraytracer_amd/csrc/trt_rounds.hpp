@@ -244,6 +244,8 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
 #if TRT_STAMP
     unsigned long long &stamp_prev = *stamp_prev_p;
 #define TRT_TRACE_STAMP(k) TRT_STAMP_AT(stamp_base + (k))
+#elif defined(TRT_MARKS)
+#define TRT_TRACE_STAMP(k) TRT_STAMP_AT(trace_##k)
 #else
 #define TRT_TRACE_STAMP(k) \
     do                     \
