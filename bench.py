@@ -201,13 +201,15 @@ def main():
     cameras = animation_cameras(width, height, args.animation) if args.animation > 0 else [scene.camera]
     camera_of = lambda step: cameras[step % len(cameras)]  # noqa: E731
     rehearsal = world > 1 and args.backend != "nccl"
-    if rehearsal:  # PyTorch-level sharding over gloo: several ranks may share one GPU, which RCCL cannot do
+    fallback_reason = None
+
+    def torch_level_renderer():  # PyTorch-level sharding: trt_render_device per rank, torch.distributed gather
         r = HipShardRenderer(scene, width, height, rank, world, local, bounces, SPP, tile_rows=args.tile_rows, depth=args.depth,
                              reserve_cus=args.reserve_cus)
-        contexts = [slot["ctx"] for slot in r.slots]
-        rowset = r.sharded.rowset
-        render = r.render                                    # -> frame tensor on rank 0
-        fetch = lambda frame: frame.cpu().numpy()            # noqa: E731
+        return r, [slot["ctx"] for slot in r.slots], r.sharded.rowset, r.render, (lambda frame: frame.cpu().numpy())
+
+    if rehearsal:  # over gloo several ranks may share one GPU, which RCCL cannot do
+        r, contexts, rowset, render, fetch = torch_level_renderer()
     else:          # the product path: trt_dist_* behind the C-ABI
         uid = None
         if world > 1:
@@ -216,12 +218,46 @@ def main():
                 box.copy_(torch.frombuffer(bytearray(hip.dist_unique_id()), dtype=torch.uint8))
             dist.broadcast(box, 0)
             uid = bytes(box.cpu().numpy().tobytes())
-        r = hip.Dist(local, scene, uid, rank, world, width, height, tile_rows=args.tile_rows, frames_in_flight=args.depth,
-                     reserved_cus=args.reserve_cus)
-        contexts = [r.context(i) for i in range(args.depth)]
-        rowset = hip.RowSet.shard(width, height, rank, world, args.tile_rows)
-        render = lambda cam: r.render(cam, bounces, SPP)     # noqa: E731  -> device address of the frame on rank 0
-        fetch = r.fetch
+        # The library's communicator meets its peers here for the first time in the life of the process: create it and push one
+        # frame through it on a side thread with a deadline, and let the ranks agree on the outcome.  If any rank failed (an
+        # error, or no frame within the deadline), every rank falls back to the PyTorch-level gather and the line says so.
+        import threading
+        made, problem = {}, []
+
+        def first_contact():
+            try:
+                if os.environ.get("TRT_BENCH_FAIL_DIST"):  # test hook for the fallback
+                    raise RuntimeError("TRT_BENCH_FAIL_DIST is set")
+                d = hip.Dist(local, scene, uid, rank, world, width, height, tile_rows=args.tile_rows, frames_in_flight=args.depth,
+                             reserved_cus=args.reserve_cus)
+                made["dist"] = d
+                frame = d.render(camera_of(0), bounces, SPP)
+                d.synchronize()
+                if rank == 0:
+                    d.fetch(frame)
+            except Exception as e:  # noqa: BLE001
+                problem.append(f"{type(e).__name__}: {e}")
+
+        worker = threading.Thread(target=first_contact, daemon=True)
+        worker.start()
+        worker.join(timeout=180.0 if world > 1 else None)
+        if worker.is_alive():
+            problem.append("no frame through trt_dist_* within 180 s")
+        ok = torch.tensor([0 if problem else 1], dtype=torch.int32, device=f"cuda:{local}")
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            r = made["dist"]
+            contexts = [r.context(i) for i in range(args.depth)]
+            rowset = hip.RowSet.shard(width, height, rank, world, args.tile_rows)
+            render = lambda cam: r.render(cam, bounces, SPP)     # noqa: E731  -> device address of the frame on rank 0
+            fetch = r.fetch
+        else:
+            fallback_reason = problem[0] if problem else "another rank failed"
+            print(f"bench: rank {rank}: C-ABI multi-GPU path unavailable ({fallback_reason}); falling back to the PyTorch-level gather", file=sys.stderr)
+            if "dist" in made and not worker.is_alive():
+                made["dist"].close()
+            r, contexts, rowset, render, fetch = torch_level_renderer()
     for c in contexts:
         c.set_kernel(args.kernel)
     ctx0 = contexts[0]
@@ -325,7 +361,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["text"] if args.sky_dim == SKY_DIM else wl["text"].replace("256^2", f"{args.sky_dim}^2"), "sharding": f"{world} x interleaved {args.tile_rows}-row tiles, 1 gather/frame",
-                       "multi_gpu_path": "PyTorch-level rehearsal (gloo)" if rehearsal else "C-ABI trt_dist_* (RCCL send/recv gather inside the library)",
+                       "multi_gpu_path": "PyTorch-level rehearsal (gloo)" if rehearsal else
+                                         ("C-ABI trt_dist_* (RCCL send/recv gather inside the library)" if fallback_reason is None else
+                                          "FALLBACK: PyTorch-level gather (torch.distributed " + args.backend + "); trt_dist_* failed: " + fallback_reason),
                        "kernel": {0: "persistent waves, synchronous rounds" + (", shading decoupled from the owning lane" if variant["decoupled"] else ""),
                                   1: "reference-order"}[args.kernel],
                        "workgroup_threads": variant["workgroup_threads"],
