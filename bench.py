@@ -386,6 +386,15 @@ def main():
                                  "frames_in_flight frames in flight, so consecutive launches overlap there.  The path is VALU-issue-bound: "
                                  "~1 algorithmic byte per ray, frac << 1 by nature (SURVEY 0, DESIGN.md 5); `traffic` and `valu` are "
                                  "COMMITTED rocprofv3 PMC results (profiles/traffic.json), not measured in this run"},
+            # SURVEY 8d, compute basis: what the REFERENCE's algorithm spends on these rays (every trace_ray call tests all N spheres
+            # and the ground: 25 N + 17 FP64 flops), over the render kernel's own duration.  The candidate tables skip most of those
+            # tests, so this is work avoided as much as work done and may exceed the FP64 vector peak; what the hardware executed is
+            # in `valu` (instructions, measured VALU busy).
+            "compute": {"basis": "reference-equivalent FP64 flops = trace_ray calls x (25 N + 17)",
+                        "flops_per_frame": (path_mean + float(np.mean(shadow_cam))) * (25 * wl["spheres"] + 17),
+                        "achieved": (path_mean + float(np.mean(shadow_cam))) * (25 * wl["spheres"] + 17) / (render_ms_avg * 1e-3) / 1e12,
+                        "unit": "TFLOP/s", "peak": 78.6, "peak_without_fma": 39.3,
+                        "peak_source": "MI355X FP64 vector: half the 157.3 TFLOP/s FP32 vector figure of MI355X_MICROARCH.md; -ffp-contract=off halves it again"},
             "valu": (prof or {}).get("valu"),
             "kernel_info": ctx0.kernel_info(),
             # one round = one path ray per lane (+ one shadow ray per light for the lanes that hit something)
