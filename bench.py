@@ -160,11 +160,11 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 production, 1 reference-order (debug)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
-    ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = 2 on one GPU, 3 on "
-                                                         "several: the gather of frame f can only get on the machine when the persistent "
-                                                         "workgroups of frame f+1 retire, so with two slots frame f+2 would wait for it; a third "
-                                                         "slot lets f+2 start meanwhile (and fills the tails of short shards: 0.229 against "
-                                                         "0.248 ms per 1/8 shard on one GPU, tools/shard_bench.py))")
+    ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = the default, 3: the "
+                                                         "next frames' workgroups fill the CUs that a frame's tail leaves idle -- on one GPU "
+                                                         "1.86 / 1.67 / 1.65 / 1.66 ms per frame with 1 / 2 / 3 / 4 -- and on several GPUs the "
+                                                         "gather of frame f can only get on the machine when the persistent workgroups of frame "
+                                                         "f+1 retire, so with two slots frame f+2 would wait for it)")
     ap.add_argument("--tile-rows", type=int, default=8, help="rows per interleaved tile of the row sharding")
     ap.add_argument("--sky-dim", type=int, default=SKY_DIM, help="cubemap face size (the frame is only verified at the default, 256)")
     ap.add_argument("--reserve-cus", type=int, default=0, help="compute units kept free of render workgroups so that the gather's kernels can "
@@ -181,7 +181,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if args.depth <= 0:
-        args.depth = 3 if world > 1 else 2
+        args.depth = 3
     workload = "c5" if args.animation > 0 else "c3"
     wl = WORKLOADS[workload]
     width, height, bounces = wl["width"], wl["height"], wl["bounces"]
