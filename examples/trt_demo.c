@@ -2,7 +2,10 @@
  * host C builds the demo scene and the orbiting camera, the MI355X produces the frame through
  * the drop-in project_scene(), and the ANSI emitter stays on the host.
  *
- *   trt_demo <skybox-directory> [frames=0 (until Ctrl-C)] [width=160] [height=48] [--no-draw]
+ *   trt_demo <skybox-directory> [frames=0 (until Ctrl-C)] [width=160] [height=48] [--no-draw] [--rgb8]
+ *
+ * --rgb8: the frame crosses PCIe as the 3 bytes per pixel the emitter makes of it (trt_render_frame_rgb8: the (int)(c*255) of
+ * TRT.c:1157-1163 done on the device) instead of as 24-byte doubles; what reaches the terminal is the same.
  *
  * The scene literals are the reference's (TRT.c:1256-1288). */
 #include <signal.h>
@@ -31,12 +34,19 @@ int main(int argc, char **argv)
 {
     if (argc < 2)
     {
-        fprintf(stderr, "usage: %s <skybox-directory> [frames] [width] [height] [--no-draw]\n", argv[0]);
+        fprintf(stderr, "usage: %s <skybox-directory> [frames] [width] [height] [--no-draw] [--rgb8]\n", argv[0]);
         return 2;
     }
     const long frames = argc > 2 ? atol(argv[2]) : 0;
     const int width = argc > 3 ? atoi(argv[3]) : 160, height = argc > 4 ? atoi(argv[4]) : 48;
-    const int draw = !(argc > 5 && strcmp(argv[5], "--no-draw") == 0);
+    int draw = 1, bytes_only = 0;
+    for (int i = 5; i < argc; i++)
+    {
+        if (strcmp(argv[i], "--no-draw") == 0)
+            draw = 0;
+        else if (strcmp(argv[i], "--rgb8") == 0)
+            bytes_only = 1;
+    }
 
     Skybox sky;
     int rc = trt_load_skybox(&sky, argv[1]);
@@ -70,8 +80,9 @@ int main(int argc, char **argv)
     trt_init_camera(&scene.camera, width, height);
 
     Screen screen = {(Vector *)malloc(sizeof(Vector) * (size_t)width * height), width, height};
+    unsigned char *rgb = (unsigned char *)malloc((size_t)width * height * 3);
     trt_emitter *emitter = NULL;
-    if (!screen.pixels || trt_emitter_create(width, height, &emitter) != TRT_HOST_OK)
+    if (!screen.pixels || !rgb || trt_emitter_create(width, height, &emitter) != TRT_HOST_OK)
         return 1;
 
     signal(SIGINT, on_sigint);
@@ -85,7 +96,13 @@ int main(int argc, char **argv)
         trt_orbit_camera(&scene.camera, t);
 
         const double before = seconds_since(&start);
-        project_scene(&scene, &screen); /* the GPU frame producer, same call as TRT.c:1339 */
+        if (!bytes_only)
+            project_scene(&scene, &screen); /* the GPU frame producer, same call as TRT.c:1339 */
+        else if (trt_render_frame_rgb8(&scene, width, height, TRT_REF_BOUNCE_LIMIT, TRT_REF_RAYS_PER_PIXEL, rgb) != TRT_OK)
+        {
+            fprintf(stderr, "trt_render_frame_rgb8: %s\n", trt_last_error());
+            return 1;
+        }
         if (frame == 0) /* device initialisation, cubemap upload and pinned staging happen in the first call */
             first_call_seconds = seconds_since(&start) - before;
         else
@@ -93,18 +110,23 @@ int main(int argc, char **argv)
 
         if (draw)
         {
-            trt_emitter_patch(emitter, &screen);
+            if (bytes_only)
+                trt_emitter_patch_rgb8(emitter, rgb);
+            else
+                trt_emitter_patch(emitter, &screen);
             trt_emitter_write(emitter, stdout);
             fputs("\033[0;0H", stdout);
             printf("%.02f fps\n", 1.0 / (seconds_since(&start) - t));
             fputs("\033[0;0H", stdout);
         }
     }
-    fprintf(stderr, "%ld frames %dx%d, frame producer %.3f ms/frame after a first call of %.1f ms (host-in/host-out, 10 bounces, 10 rays per pixel)\n",
-            frame, width, height, frame > 1 ? 1e3 * producer_seconds / (frame - 1) : 0.0, 1e3 * first_call_seconds);
+    fprintf(stderr, "%ld frames %dx%d, frame producer %.3f ms/frame after a first call of %.1f ms (host-in/host-out%s, 10 bounces, 10 rays per pixel)\n",
+            frame, width, height, frame > 1 ? 1e3 * producer_seconds / (frame - 1) : 0.0, 1e3 * first_call_seconds,
+            bytes_only ? " as RGB8" : "");
 
     trt_emitter_destroy(emitter);
     free(screen.pixels);
+    free(rgb);
     trt_free_skybox(&sky);
     trt_shutdown();
     return 0;

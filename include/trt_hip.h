@@ -48,6 +48,12 @@ void project_scene(Scene *scene, Screen *screen);
 /* project_scene with the two macros as run-time values (TRT.c:54, TRT.c:58).  Host in, host out. */
 int trt_render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_per_pixel);
 
+/* The same frame as the bytes the emitter makes of it: rgb[(row*width + col)*3 + channel] = (int)(colour*255), the
+ * conversion of buffered_draw_screen (TRT.c:1157-1163) done on the device, so that 3 bytes per pixel cross PCIe instead of 24.
+ * For hosts whose only consumer of the frame is the terminal emitter (trt_emitter_patch_rgb8, trt_host.h).  Colours outside
+ * [0, 1) convert as the reference's cast does on x86-64. */
+int trt_render_frame_rgb8(const Scene *scene, int width, int height, int bounce_limit, int rays_per_pixel, unsigned char *rgb);
+
 /* Default-context management for the two calls above.  trt_init is optional (device 0 otherwise). */
 int trt_init(int device);
 int trt_shutdown(void);
@@ -112,6 +118,10 @@ int trt_quantize_device(trt_context *ctx, const void *d_pixels, size_t num_pixel
 /* Same as trt_render_device but into HOST memory (synchronous; pinned staging inside). */
 int trt_render_host(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit,
                     int rays_per_pixel, Vector *pixels);
+
+/* trt_render_host followed by the emitter's (int)(c*255) on the device: 3 bytes per pixel to HOST memory (synchronous). */
+int trt_render_host_rgb8(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit, int rays_per_pixel,
+                         unsigned char *rgb);
 
 int trt_synchronize(trt_context *ctx);
 

@@ -142,6 +142,7 @@ struct trt_context
     int grids_built_for[2] = {-1, -1};
     DeviceBuffer<uint32_t> d_sky;
     DeviceBuffer<double> d_ior; // refraction extension: per sphere, > 0 = index of refraction
+    DeviceBuffer<unsigned char> d_rgb8; // trt_render_host_rgb8: the quantised frame before it crosses PCIe
     int ior_count = 0;          // 0 = off (the reference's path)
     DeviceBuffer<unsigned long long> d_counters;
     DeviceBuffer<unsigned int> d_queue;
@@ -783,6 +784,7 @@ extern "C" int trt_destroy(trt_context *ctx)
     ctx->d_samples.release();
     ctx->d_samples_alt.release();
     ctx->d_fb.release();
+    ctx->d_rgb8.release();
     ctx->d_cull.release();
     ctx->d_dir_lists.release();
     ctx->d_point_lists.release();
@@ -1627,25 +1629,16 @@ extern "C" int trt_invalidate_skybox(void)
     return TRT_OK;
 }
 
-extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_per_pixel)
+// The caller owns the scene and may have edited it since the last frame (main() rewrites the camera every frame,
+// TRT.c:1327-1336): primitives are a few KB and are re-sent; the 6*dim*dim texels only when the face pointers, the dimension
+// or the texel stamp changed.  With g_default_mutex held.
+static int refresh_default_scene(trt_context *ctx, const Scene *scene)
 {
-    if (!scene || !screen || !screen->pixels)
-        return fail(TRT_ERR_ARGUMENT, "NULL argument");
-    if (screen->width <= 0 || screen->height <= 0)
-        return fail(TRT_ERR_ARGUMENT, "screen %d x %d", screen->width, screen->height);
-    std::lock_guard<std::mutex> turn(g_default_mutex);
-    trt_context *ctx;
-    int rc = default_context(&ctx);
-    if (rc)
-        return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     const double t_begin = host_now_ms();
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    // the caller owns the scene and may have edited it since the last frame (main() rewrites the camera
-    // every frame, TRT.c:1327-1336): primitives are a few KB and are re-sent; the 6*dim*dim texels only
-    // when the face pointers or the dimension changed
     ctx->have_scene = false;
-    rc = upload_primitives(ctx, scene);
+    int rc = upload_primitives(ctx, scene);
     if (rc)
         return rc;
     bool same_sky = ctx->sky_dim == scene->skybox.dim;
@@ -1661,8 +1654,80 @@ extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_l
     ctx->have_scene = true;
     if (print_host_times())
         fprintf(stderr, "trt_render_frame: scene upload %.3f ms\n", host_now_ms() - t_begin);
+    return TRT_OK;
+}
+
+extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_per_pixel)
+{
+    if (!scene || !screen || !screen->pixels)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (screen->width <= 0 || screen->height <= 0)
+        return fail(TRT_ERR_ARGUMENT, "screen %d x %d", screen->width, screen->height);
+    std::lock_guard<std::mutex> turn(g_default_mutex);
+    trt_context *ctx;
+    int rc = default_context(&ctx);
+    if (rc)
+        return rc;
+    rc = refresh_default_scene(ctx, scene);
+    if (rc)
+        return rc;
     const trt_rowset whole = {screen->width, screen->height, screen->height, 0, 1};
     return trt_render_host(ctx, &scene->camera, &whole, bounce_limit, rays_per_pixel, screen->pixels);
+}
+
+extern "C" int trt_render_host_rgb8(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit, int rays_per_pixel,
+                                    unsigned char *rgb)
+{
+    if (!ctx || !rgb)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (!rowset_valid(rows))
+        return fail(TRT_ERR_ARGUMENT, "invalid rowset");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t count = (size_t)trt_rowset_rows(rows) * rows->width;
+    if (count == 0)
+        return TRT_OK;
+    HIP_TRY(ctx->d_fb.reserve(count * 3));
+    HIP_TRY(ctx->d_rgb8.reserve(count * 3));
+    if (ctx->h_staging_bytes < count * 3)
+    {
+        if (ctx->h_staging)
+            (void)hipHostFree(ctx->h_staging);
+        ctx->h_staging = nullptr;
+        ctx->h_staging_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_staging, count * 3, hipHostMallocDefault));
+        ctx->h_staging_bytes = count * 3;
+    }
+    const double t_begin = host_now_ms();
+    int rc = trt_render_device(ctx, camera, rows, bounce_limit, rays_per_pixel, ctx->d_fb.ptr, count * sizeof(Vector));
+    if (rc)
+        return rc;
+    rc = trt_quantize_device(ctx, ctx->d_fb.ptr, count, ctx->d_rgb8.ptr); // (int)(c*255), TRT.c:1157-1163, on the device
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_staging, ctx->d_rgb8.ptr, count * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(rgb, ctx->h_staging, count * 3);
+    if (print_host_times())
+        fprintf(stderr, "trt_render_host_rgb8: %.3f ms for %zu pixels\n", host_now_ms() - t_begin, count);
+    return TRT_OK;
+}
+
+extern "C" int trt_render_frame_rgb8(const Scene *scene, int width, int height, int bounce_limit, int rays_per_pixel, unsigned char *rgb)
+{
+    if (!scene || !rgb)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (width <= 0 || height <= 0)
+        return fail(TRT_ERR_ARGUMENT, "screen %d x %d", width, height);
+    std::lock_guard<std::mutex> turn(g_default_mutex);
+    trt_context *ctx;
+    int rc = default_context(&ctx);
+    if (rc)
+        return rc;
+    rc = refresh_default_scene(ctx, scene);
+    if (rc)
+        return rc;
+    const trt_rowset whole = {width, height, height, 0, 1};
+    return trt_render_host_rgb8(ctx, &scene->camera, &whole, bounce_limit, rays_per_pixel, rgb);
 }
 
 extern "C" void project_scene(Scene *scene, Screen *screen)

@@ -47,6 +47,7 @@ _VP, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
 SYMBOLS = {
     "project_scene": (None, [C.POINTER(L.Scene), C.POINTER(L.Screen)]),
     "trt_render_frame": (_I, [C.POINTER(L.Scene), C.POINTER(L.Screen), _I, _I]),
+    "trt_render_frame_rgb8": (_I, [C.POINTER(L.Scene), _I, _I, _I, _I, _VP]),
     "trt_init": (_I, [_I]),
     "trt_shutdown": (_I, []),
     "trt_upload_skybox": (_I, [C.POINTER(L.Skybox)]),
@@ -60,6 +61,7 @@ SYMBOLS = {
     "trt_render_device": (_I, [_VP, C.POINTER(L.Camera), C.POINTER(RowSet), _I, _I, _VP, _SZ]),
     "trt_quantize_device": (_I, [_VP, _VP, _SZ, _VP]),
     "trt_render_host": (_I, [_VP, C.POINTER(L.Camera), C.POINTER(RowSet), _I, _I, _VP]),
+    "trt_render_host_rgb8": (_I, [_VP, C.POINTER(L.Camera), C.POINTER(RowSet), _I, _I, _VP]),
     "trt_synchronize": (_I, [_VP]),
     "trt_kernel_times": (_I, [_VP, C.POINTER(C.c_float), _I]),
     "trt_render_kernel_times": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), _I]),
@@ -263,6 +265,14 @@ class Context:
                                      out.ctypes.data))
         return out
 
+    def render_host_rgb8(self, camera_array, rows, bounce_limit, rays_per_pixel):
+        """the frame as the emitter's bytes, (int)(c*255) done on the device: uint8 [rows, width, 3] (trt_render_host_rgb8)"""
+        n = lib().trt_rowset_rows(C.byref(rows))
+        out = np.zeros((n, rows.width, 3), dtype=np.uint8)
+        cam = camera_struct(camera_array)
+        _check(lib().trt_render_host_rgb8(self._h, C.byref(cam), C.byref(rows), bounce_limit, rays_per_pixel, out.ctypes.data))
+        return out
+
     def synchronize(self):
         _check(lib().trt_synchronize(self._h))
 
@@ -339,6 +349,14 @@ def render_frame(scene_data, width, height, bounce_limit=10, rays_per_pixel=10):
     screen, pixels = new_screen(width, height)
     _check(lib().trt_render_frame(C.byref(scene), C.byref(screen), bounce_limit, rays_per_pixel))
     return pixels
+
+
+def render_frame_rgb8(scene_data, width, height, bounce_limit=10, rays_per_pixel=10):
+    """Host-in, emitter-bytes-out frame: uint8 [height, width, 3] = (int)(c*255) formed on the device (trt_render_frame_rgb8)."""
+    scene = scene_data.as_scene()
+    out = np.zeros((height, width, 3), dtype=np.uint8)
+    _check(lib().trt_render_frame_rgb8(C.byref(scene), width, height, bounce_limit, rays_per_pixel, out.ctypes.data))
+    return out
 
 
 def project_scene(scene_data, width, height):

@@ -280,6 +280,35 @@ def test_gpu_frame_through_the_host_emitter_matches_reference_bytes(ctx):
     assert em.bytes() == want
 
 
+def test_host_rgb8_entries_feed_the_emitter_the_reference_bytes(ctx):
+    """trt_render_host_rgb8 / trt_render_frame_rgb8 (3 bytes per pixel across PCIe): the bytes are (int)(c*255) of the very
+    framebuffer the f64 path produces -- the reference's golden frame -- shards included, and the host emitter turns them into
+    the reference's screenbuffer."""
+    import zlib
+    from terminalraytracer_amd import host
+    case = next(c for c in SMALL if c["name"] == "demo_160x48_b4")
+    scene = T.golden_scene(case)
+    ctx.set_kernel(hip.Context.PRODUCTION)
+    ctx.set_scene(scene)
+    want_rgb = T.oracle_rgb8(T.golden_fb(case))
+    whole = ctx.render_host_rgb8(scene.camera, hip.RowSet.whole(160, 48), 4, 10)
+    assert whole.dtype == np.uint8 and np.array_equal(whole.reshape(-1), np.asarray(want_rgb).reshape(-1))
+    rows = hip.RowSet.shard(160, 48, 1, 3, 5)
+    part = ctx.render_host_rgb8(scene.camera, rows, 4, 10)
+    mine = [hip.lib().trt_rowset_frame_row(C.byref(rows), i) for i in range(part.shape[0])]
+    assert np.array_equal(part, whole[mine])
+    through_default = hip.render_frame_rgb8(scene, 160, 48, 4, 10)
+    assert np.array_equal(through_default, whole)
+    em = host.Emitter(160, 48)
+    em.patch_rgb8(through_default)
+    assert em.bytes() == zlib.decompress(open(T.GOLDEN + "/emit_demo_160x48_b4.bin.z", "rb").read())
+    big = T.golden_full()["c3_1080p_64sph_b8"]  # a frame large enough for the banded f64 path: same bytes either way
+    scene = T.full_scene(big)
+    ctx.set_scene(scene)
+    rgb = ctx.render_host_rgb8(scene.camera, hip.RowSet.whole(1920, 1080), 8, 10)
+    assert T.fnv(rgb) == big["rgb8_fnv"]
+
+
 @pytest.mark.parametrize("through_rccl", [False, True], ids=["plain", "one_rank_rccl_communicator"])
 def test_c_abi_dist_renderer_world_of_one(ctx, through_rccl):
     """trt_dist_* (include/trt_hip.h section 3) with one rank: the row tiles, the frame pipeline (three frames in flight,

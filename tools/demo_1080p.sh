@@ -13,4 +13,6 @@ PY
 if [ -n "$TRT_PRINT_HOST_TIMES" ]; then ./examples/trt_demo "$tmp/colors" 6 1920 1080 --no-draw 2>&1 | tail -9; ./examples/trt_demo "$tmp/colors" 6 480 280 --no-draw 2>&1 | tail -6; rm -rf "$tmp"; exit 0; fi
 ./examples/trt_demo "$tmp/colors" 30 1920 1080 --no-draw
 ./examples/trt_demo "$tmp/colors" 200 480 280 --no-draw
+./examples/trt_demo "$tmp/colors" 30 1920 1080 --no-draw --rgb8
+./examples/trt_demo "$tmp/colors" 200 480 280 --no-draw --rgb8
 rm -rf "$tmp"
