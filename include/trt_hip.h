@@ -171,11 +171,14 @@ int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres);
 /* Shading decoupled from the lane that owns the sample (render_rounds_kernel<.., .., true>): the hits of a
  * wave become tasks in a ring in LDS and are shaded 64 at a time, whichever lanes they came from, so that the shadow rays run
  * with ~96 % of the lanes busy instead of ~61 % (the share of path rays that hit something).  The ring costs about what one
- * light's idle lanes cost: mode -1 (default) uses it for scenes with two lights or more, when the rings fit in LDS beside
- * the scene without costing a resident wave (up to ~100 spheres); 0: never; 1: whenever the rings fit.  Frames are
- * bit-identical in every mode.  Environment TRT_COMPACTION=-1|0|1 sets the default of new contexts. */
+ * light's idle lanes cost, and its 1024-thread workgroups suit large launches: mode -1 (default) uses it for scenes with two
+ * lights or more and launches of 16 M samples or more (a 1080p frame at 10 rays per pixel is 20.7 M; row shards of 1/2 and
+ * less stay on the plain rounds), when the rings fit in LDS beside the scene without costing a resident wave (up to ~100
+ * spheres); 0: never; 1: whenever the rings fit.  Frames are bit-identical in every mode.  Environment TRT_COMPACTION=-1|0|1
+ * sets the default of new contexts. */
 int trt_set_compaction(trt_context *ctx, int mode);
-/* Which form the next frame of the current scene runs: *decoupled 1 / 0, and the threads of a workgroup (1024 / 256). */
+/* Which form a frame of the current scene and of the most recent launch's size runs (a whole large frame before the first
+ * launch): *decoupled 1 / 0, and the threads of a workgroup (1024 / 256). */
 int trt_render_variant(trt_context *ctx, int *decoupled, int *workgroup_threads);
 
 /* Copy the path rays' tables to the host (tests: the device-built lists must equal the host reference builder's): list

@@ -158,6 +158,7 @@ struct trt_context
     int kernel = 0; // 0 production (persistent waves, synchronous rounds), 1 reference-order
     int rounds_blocks_per_cu = 0;
     int compact_blocks_per_cu = 0; // the same for the kernel with shading rings in LDS
+    long last_units = 0;           // samples of the most recent launch (trt_render_variant / trt_kernel_info describe that launch's kernel)
     int compaction = -1;           // trt_set_compaction: -1 when it costs no occupancy, 0 never, 1 whenever the rings fit
     size_t occupancy_for_lds = (size_t)-1;
     hipEvent_t ev_chunk[16]; // hand-over of framebuffer chunks to the host copy threads (trt_render_host)
@@ -193,14 +194,19 @@ size_t compact_lds_bytes(const trt::SceneView &s, int spp)
     return sizeof(double) * (compact_ring_at(s, spp) + (size_t)(trt::kCompactBlock / 64) * trt::kRingDoubles);
 }
 
-// Does the next frame of this context run the kernel with the shading decoupled from the owning lane (COMPACT, trt_rounds.hpp)?
-// Measured (profiles/r02/n_compaction.md): 6 % faster with the two lights of the BASELINE scenes, 10 / 12 / 15 / 17 % with
-// 3 / 4 / 6 / 8; the ring costs about what one light's idle lanes cost.
-static bool renders_decoupled(const trt_context *ctx)
+// Does a frame of `units` samples on this context run the kernel with the shading decoupled from the owning lane (COMPACT,
+// trt_rounds.hpp)?  Measured (profiles/r02/n_compaction.md): 6 % faster with the two lights of the BASELINE scenes, 10 / 12 /
+// 15 / 17 % with 3 / 4 / 6 / 8; the ring costs about what one light's idle lanes cost.  Its 1024-thread workgroups hold a
+// whole CU until their last wave retires, which pipelined frames feel on SMALL launches (profiles/r02/t_shards.txt: a 1/8
+// shard of the 1080p frame, three in flight, 0.249 ms decoupled against 0.218 plain; half a frame 0.884 against 0.871; the
+// whole frame 1.630 against 1.685): by default only launches of 16 M samples or more are decoupled.
+constexpr long kCompactionMinUnits = 16L << 20;
+
+static bool renders_decoupled(const trt_context *ctx, long units)
 {
     if (ctx->kernel != 0 || ctx->ior_count || ctx->compact_blocks_per_cu <= 0 || ctx->compaction == 0)
         return false;
-    const bool pays = ctx->scene.num_dir + ctx->scene.num_point >= kCompactionMinLights &&
+    const bool pays = ctx->scene.num_dir + ctx->scene.num_point >= kCompactionMinLights && units >= kCompactionMinUnits &&
                       ctx->compact_blocks_per_cu * trt::kCompactBlock >= ctx->rounds_blocks_per_cu * trt::kPersistentBlock;
     return ctx->compaction > 0 || pays;
 }
@@ -915,7 +921,7 @@ extern "C" int trt_render_variant(trt_context *ctx, int *decoupled, int *workgro
 {
     if (!ctx)
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
-    const bool d = ctx->have_scene && renders_decoupled(ctx);
+    const bool d = ctx->have_scene && renders_decoupled(ctx, ctx->last_units > 0 ? ctx->last_units : kCompactionMinUnits);
     if (decoupled)
         *decoupled = d ? 1 : 0;
     if (workgroup_threads)
@@ -1179,7 +1185,8 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
         // shading decoupled from the owning lane (COMPACT, trt_rounds.hpp) when the rings fit in LDS: by default only if they
         // cost no resident wave and the scene has lights enough to pay for them.
-        const bool compact = renders_decoupled(ctx);
+        const bool compact = renders_decoupled(ctx, units);
+        ctx->last_units = units;
         trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0),
                                                                 ctx->rounds_blocks_per_cu, units);
         if (compact)
@@ -1424,7 +1431,7 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
     if (!ctx)
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    const bool decoupled = ctx->have_scene && renders_decoupled(ctx);
+    const bool decoupled = ctx->have_scene && renders_decoupled(ctx, ctx->last_units > 0 ? ctx->last_units : kCompactionMinUnits);
     const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel
                      : decoupled      ? (const void *)trt::render_rounds_kernel<false, false, true>
                                       : (const void *)trt::render_rounds_kernel<false>;

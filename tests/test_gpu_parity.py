@@ -897,19 +897,27 @@ def test_compaction_fills_the_shadow_lanes_of_the_bench_frame(ctx):
 
 
 def test_compaction_default_policy(ctx):
-    """trt_set_compaction(-1): on from two lights up when the rings fit in LDS beside the scene, off for a single light (a wash)
-    and for a 256-sphere scene (no room: forcing it on changes nothing either); every frame equals the oracle's."""
+    """trt_set_compaction(-1): on for launches of 16 M samples or more of scenes with two lights or more whose rings fit in LDS
+    (the bench frame: the test above); off for small launches (pipelined shards are faster on 256-thread workgroups), for a
+    single light (a wash) and for a 256-sphere scene (no room: forcing it on changes nothing either).  Every frame equals the
+    oracle's."""
     w, h = 480, 270
     base = S.synth_scene(64, T.sky("synth"), T.bench_camera(w, h, 2.5), seed=7)
-    one = S.SceneData(base.spheres, base.ground, base.dir_lights, base.point_lights[:0], base.camera, base.sky)
     big = S.synth_scene(256, T.sky("synth"), T.bench_camera(w, h, 2.5), seed=7)
-    assert len(base.dir_lights) + len(base.point_lights) == 2 and len(one.dir_lights) == 1
-    for scene, kernel, decoupled in ((base, hip.Context.PRODUCTION, True), (one, hip.Context.PRODUCTION, False), (one, COMPACT, True),
-                                     (big, hip.Context.PRODUCTION, False), (big, COMPACT, False)):
+    assert len(base.dir_lights) + len(base.point_lights) == 2
+    for scene, kernel, decoupled in ((base, hip.Context.PRODUCTION, False), (base, COMPACT, True), (big, hip.Context.PRODUCTION, False),
+                                     (big, COMPACT, False)):
         frame, activity = _shadow_lane_activity(ctx, scene, w, h, 8, 10, kernel)
         assert (activity > 0.85) == decoupled and (decoupled or activity < 0.8), (len(scene.spheres), kernel, activity)
+        assert ctx.render_variant()["decoupled"] == decoupled
         want, _ = T.oracle_render(scene, w, h, 8, 10)
         assert np.array_equal(bits(frame), bits(want))
+    # at the bench frame's size: two lights decoupled (the test above), one light not
+    case = T.golden_full()["c3_1080p_64sph_b8"]
+    full = T.full_scene(case)
+    one = S.SceneData(full.spheres, full.ground, full.dir_lights, full.point_lights[:0], full.camera, full.sky)
+    _, activity = _shadow_lane_activity(ctx, one, case["width"], case["height"], 8, 10, hip.Context.PRODUCTION)
+    assert activity < 0.8 and not ctx.render_variant()["decoupled"]
 
 
 @pytest.mark.parametrize("seed", range(16))
