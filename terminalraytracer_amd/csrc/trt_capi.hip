@@ -1185,8 +1185,12 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         f.spp_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rays_per_pixel - 1) / (unsigned)rays_per_pixel, 0xffffffffull);
         // shading decoupled from the owning lane (COMPACT, trt_rounds.hpp) when the rings fit in LDS: by default only if they
         // cost no resident wave and the scene has lights enough to pay for them.
-        const bool compact = renders_decoupled(ctx, units);
+        // (the occupancy figures were taken for 64 rays per pixel: with more, the jitter table may push the rings out of LDS)
+        const bool compact = renders_decoupled(ctx, units) && compact_lds_bytes(ctx->scene, rays_per_pixel) <= (size_t)ctx->lds_limit;
         ctx->last_units = units;
+        if (trt::rounds_lds_bytes(ctx->scene, rays_per_pixel) > (size_t)ctx->lds_limit)
+            return fail(TRT_ERR_CAPACITY, "scene and %d rays per pixel need %zu B of LDS staging, device offers %d", rays_per_pixel,
+                        trt::rounds_lds_bytes(ctx->scene, rays_per_pixel), ctx->lds_limit);
         trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0),
                                                                 ctx->rounds_blocks_per_cu, units);
         if (compact)
