@@ -660,6 +660,41 @@ constexpr int kRingTasks = 128;                            // >= 63 carried over
 constexpr int kRingDoubles = 7 * kRingTasks + kRingTasks / 2 + 3 * 64; // point(3) normal(3) weight(1) as arrays of doubles, material as ints;
                                                                         // then per LANE the direction of its next path ray while the wave shades
 
+// The kernel's arguments live in the kernarg segment (constant address space, read with scalar loads).  Held in SGPRs for the
+// whole kernel they do not fit: the compiler spilt ~75 of them to VGPR lanes and read ~110 back per round with v_readlane, a
+// tenth of the VALU instructions.  TRT_FRESH_ARGS re-reads, at the head of a stage, the arguments that stage uses (the copies
+// shadow the kernel's parameters; unused fields are never loaded): a few s_load per stage instead of the v_readlanes, and
+// nothing to keep alive between stages.  The empty asm makes the pointer opaque so that the loads stay where they are written.
+#define CONSTANT_AS __attribute__((address_space(4)))
+constexpr size_t kArgScene = 0;
+constexpr size_t kArgCull = (kArgScene + sizeof(SceneView) + alignof(CullView) - 1) / alignof(CullView) * alignof(CullView);
+constexpr size_t kArgFrame = (kArgCull + sizeof(CullView) + alignof(FrameView) - 1) / alignof(FrameView) * alignof(FrameView);
+constexpr size_t kArgGrids = (kArgFrame + sizeof(FrameView) + alignof(GridView) - 1) / alignof(GridView) * alignof(GridView);
+template <class T>
+TRT_DEV T load_kernel_argument(const char CONSTANT_AS *at)
+{
+    static_assert(sizeof(T) % 8 == 0 && alignof(T) == 8, "argument structs are whole 64-bit words");
+    T out;
+    const unsigned long long CONSTANT_AS *src = (const unsigned long long CONSTANT_AS *)at;
+    unsigned long long *dst = (unsigned long long *)&out;
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 8; i++)
+        dst[i] = src[i];
+    return out;
+}
+#define TRT_FRESH_ARGS                                                                             \
+    const char CONSTANT_AS *fresh_ = (const char CONSTANT_AS *)__builtin_amdgcn_kernarg_segment_ptr(); \
+    asm volatile("" : "+s"(fresh_));                                                               \
+    const SceneView s = load_kernel_argument<SceneView>(fresh_ + kArgScene);                       \
+    const CullView cull = load_kernel_argument<CullView>(fresh_ + kArgCull);                       \
+    const FrameView f = load_kernel_argument<FrameView>(fresh_ + kArgFrame);                       \
+    const GridView grids = load_kernel_argument<GridView>(fresh_ + kArgGrids);                     \
+    const int n = s.num_spheres, nd = s.num_dir, nl = s.num_dir + s.num_point;                     \
+    const unsigned pixels_here = (unsigned)f.local_rows * (unsigned)f.width;                       \
+    const unsigned total = pixels_here * (unsigned)f.spp;                                          \
+    const d3 gp = load3(s.ground), gn = load3(s.ground + 3);                                       \
+    (void)n, (void)nd, (void)nl, (void)total, (void)pixels_here, (void)gp, (void)gn, (void)cull, (void)grids
+
 #ifdef TRT_NATURAL
 constexpr int kCompactBlock = 256;
 #else
@@ -715,6 +750,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         TRT_STAMP_AT(22); // loop edge
         // =============== hand out work units; primary rays of new samples (TRT.c:981-1016) ===============
         {
+            TRT_FRESH_ARGS;
             const unsigned long long need = __ballot(want_unit);
             if (need)
             {
@@ -785,17 +821,23 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         if (COUNT && alive)
             tally.path++;
         TRT_STAMP_AT(1); // unit(next_dir)
-        const PathHit hit = path_stage<COUNT, REFRACT>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside);
+        PathHit hit;
+        {
+            TRT_FRESH_ARGS;
+            hit = path_stage<COUNT, REFRACT>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside);
+        }
         if constexpr (COMPACT)
         {
             const bool path_hit = hit.hit, path_sky = hit.sky;
             bool end_sample = path_sky;
             uint32_t sky_t = 0;
+            const double weight_before = weight;
+            {
+            TRT_FRESH_ARGS;
             if (path_sky)
                 sky_t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f); // TRT.c:858-867; added to the sample after the colours still on their way
             // ---- a hit becomes a task; what does not depend on its colour happens now (TRT.c:1036-1038, :1054) ----
             const unsigned long long hits = __ballot(path_hit);
-            const double weight_before = weight;
             if (hits)
             {
                 if (path_hit)
@@ -816,6 +858,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
                 }
                 q_tail += (unsigned)__builtin_popcountll(hits);
             }
+            }
             if (alive)
                 weight_sum += weight_before; // TRT.c:1034 (a sample that ends is normalised by this sum, one that goes on carries it)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the ring is written by some lanes and read by others
@@ -824,6 +867,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
             // are at the head, fewer than 64) or 64 wait.  At most 63 stay behind, so 63 + 64 is the most the ring ever holds. ----
             if (q_head != q_tail && ((int)(q_old - q_head) > 0 || q_tail - q_head >= 64u))
             {
+                TRT_FRESH_ARGS;
                 const unsigned take = q_tail - q_head < 64u ? q_tail - q_head : 64u;
                 const bool has = (unsigned)lane < take;
                 const unsigned at = (q_head + (unsigned)lane) & (kRingTasks - 1);
@@ -882,6 +926,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
                 const double q = 1.0 / weight_sum;
                 if (finish)
                 {
+                    TRT_FRESH_ARGS;
                     unsigned slot = slot_id;
                     asm volatile("" : "+v"(slot)); // the address is formed here, not kept as 64 bits for the life of the sample
                     double *out = f.samples + (size_t)slot * 3;
@@ -903,6 +948,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         double weight_sum_new = weight_sum + weight; // TRT.c:1034
         if (path_sky)
         { // TRT.c:858-867, :1044-1048: colour = texel, the sample ends here
+            TRT_FRESH_ARGS;
             const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f);
             const d3 color = d3{L.b255[t & 0xFF], L.b255[(t >> 8) & 0xFF], L.b255[(t >> 16) & 0xFF]};
             sample = add(sample, scale(color, weight));
@@ -920,7 +966,10 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
             // ===================================== S(i): shadow rays =====================================
             if (COUNT && __any(path_hit))
                 tally.passes++;
-            lit = shadow_stage<COUNT>(L, cull, grids, n, nd, nl, o, h_normal, h_mat, path_hit, gp, gn, tally);
+            {
+                TRT_FRESH_ARGS;
+                lit = shadow_stage<COUNT>(L, cull, grids, n, nd, nl, o, h_normal, h_mat, path_hit, gp, gn, tally);
+            }
         }
         else
         {
@@ -965,6 +1014,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         // ======================================= END of the bounce =======================================
         if (path_hit)
         { // TRT.c:960-962 then :1034-1048
+            TRT_FRESH_ARGS;
             d3 color = d3{clampd(lit.x, 0.0, 1.0), clampd(lit.y, 0.0, 1.0), clampd(lit.z, 0.0, 1.0)};
             color = scale(color, weight);
             weight *= L.mat[h_mat * 5 + 3];
@@ -987,6 +1037,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
             const double q = 1.0 / weight_sum_new;
             if (end_sample)
             {
+                TRT_FRESH_ARGS;
                 double *out = f.samples + (size_t)slot_id * 3;
                 out[0] = sample.x * q; // plain stores: non-temporal ones (keeping the 498 MB stream out of L2) measured no different
                 out[1] = sample.y * q;
