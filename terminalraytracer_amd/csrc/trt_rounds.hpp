@@ -682,13 +682,48 @@ TRT_DEV T load_kernel_argument(const char CONSTANT_AS *at)
         dst[i] = src[i];
     return out;
 }
+// A pointer that was read from memory is "generic" to the compiler: loads and stores through it would be FLAT instructions.
+// Every pointer in the argument structs is a device-memory address: say so (a round trip through the global address space,
+// from which the compiler's address-space inference takes it).
+template <class T>
+TRT_DEV T *in_device_memory(T *p)
+{
+    T __attribute__((address_space(1))) *g = (T __attribute__((address_space(1))) *)p;
+    asm("" : "+s"(g)); // keeps the pair of casts from being folded back into the generic pointer
+    return (T *)g;
+}
+TRT_DEV SceneView in_device_memory(SceneView v)
+{
+    v.spheres = in_device_memory(v.spheres), v.dir_lights = in_device_memory(v.dir_lights), v.point_lights = in_device_memory(v.point_lights);
+    v.sky = in_device_memory(v.sky);
+    return v;
+}
+TRT_DEV CullView in_device_memory(CullView v)
+{
+    v.table = in_device_memory(v.table);
+    return v;
+}
+TRT_DEV FrameView in_device_memory(FrameView v)
+{
+    v.jitter = in_device_memory(v.jitter), v.col_x = in_device_memory(v.col_x), v.row_y = in_device_memory(v.row_y);
+    v.samples = in_device_memory(v.samples), v.out = in_device_memory(v.out), v.ior = in_device_memory(v.ior);
+    v.counters = in_device_memory(v.counters), v.queue = in_device_memory(v.queue);
+    return v;
+}
+TRT_DEV GridView in_device_memory(GridView v)
+{
+    v.dir = in_device_memory(v.dir), v.point = in_device_memory(v.point);
+    v.dir_lists = in_device_memory(v.dir_lists), v.point_lists = in_device_memory(v.point_lists);
+    v.path_lists = in_device_memory(v.path_lists), v.pool = in_device_memory(v.pool), v.sphere_fam = in_device_memory(v.sphere_fam);
+    return v;
+}
 #define TRT_FRESH_ARGS                                                                             \
     const char CONSTANT_AS *fresh_ = (const char CONSTANT_AS *)__builtin_amdgcn_kernarg_segment_ptr(); \
     asm volatile("" : "+s"(fresh_));                                                               \
-    const SceneView s = load_kernel_argument<SceneView>(fresh_ + kArgScene);                       \
-    const CullView cull = load_kernel_argument<CullView>(fresh_ + kArgCull);                       \
-    const FrameView f = load_kernel_argument<FrameView>(fresh_ + kArgFrame);                       \
-    const GridView grids = load_kernel_argument<GridView>(fresh_ + kArgGrids);                     \
+    const SceneView s = in_device_memory(load_kernel_argument<SceneView>(fresh_ + kArgScene));     \
+    const CullView cull = in_device_memory(load_kernel_argument<CullView>(fresh_ + kArgCull));     \
+    const FrameView f = in_device_memory(load_kernel_argument<FrameView>(fresh_ + kArgFrame));     \
+    const GridView grids = in_device_memory(load_kernel_argument<GridView>(fresh_ + kArgGrids));   \
     const int n = s.num_spheres, nd = s.num_dir, nl = s.num_dir + s.num_point;                     \
     const unsigned pixels_here = (unsigned)f.local_rows * (unsigned)f.width;                       \
     const unsigned total = pixels_here * (unsigned)f.spp;                                          \
