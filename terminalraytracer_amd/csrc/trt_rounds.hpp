@@ -670,6 +670,17 @@ constexpr size_t kArgScene = 0;
 constexpr size_t kArgCull = (kArgScene + sizeof(SceneView) + alignof(CullView) - 1) / alignof(CullView) * alignof(CullView);
 constexpr size_t kArgFrame = (kArgCull + sizeof(CullView) + alignof(FrameView) - 1) / alignof(FrameView) * alignof(FrameView);
 constexpr size_t kArgGrids = (kArgFrame + sizeof(FrameView) + alignof(GridView) - 1) / alignof(GridView) * alignof(GridView);
+// the explicit arguments of a kernel sit in the kernarg segment like the members of a struct, from offset 0
+struct RenderKernelArguments
+{
+    SceneView s;
+    CullView cull;
+    FrameView f;
+    GridView grids;
+};
+static_assert(offsetof(RenderKernelArguments, cull) == kArgCull && offsetof(RenderKernelArguments, f) == kArgFrame &&
+                  offsetof(RenderKernelArguments, grids) == kArgGrids,
+              "TRT_FRESH_ARGS reads the kernel's arguments at these offsets");
 template <class T>
 TRT_DEV T load_kernel_argument(const char CONSTANT_AS *at)
 {
