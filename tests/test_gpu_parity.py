@@ -946,3 +946,16 @@ def test_compaction_on_fuzzed_scenes_with_many_lights(ctx, seed):
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(bits(got[finite]), bits(want[finite]))
     assert counts == (st.path_rays, st.shadow_rays)
     assert np.array_equal(bits(render(ctx, scene, w, h, b, spp, COMPACT)), bits(got))  # and without the counting variant
+
+
+def test_render_kernels_keep_four_waves_per_simd(ctx):
+    """Occupancy is part of the design: the plain rounds at <= 128 VGPRs in 256-thread workgroups, four to
+    a CU; the decoupled kernel at <= 128 in one 1024-thread workgroup per CU.  hipFuncGetAttributes / the occupancy query say so
+    for the kernel that the next frame runs."""
+    case = T.golden_full()["c3_1080p_64sph_b8"]
+    scene = T.full_scene(case)
+    for kernel, threads, blocks in ((PLAIN, 256, 4), (COMPACT, 1024, 1)):
+        render(ctx, scene, 64, 36, 2, 1, kernel)
+        info, variant = ctx.kernel_info(), ctx.render_variant()
+        assert variant == {"decoupled": kernel == COMPACT, "workgroup_threads": threads}
+        assert info["vgprs"] <= 128 and info["max_blocks_per_cu"] == blocks, (kernel, info)
