@@ -164,6 +164,21 @@ int trt_set_light_grids(trt_context *ctx, int directional_cells, int point_cells
  * 0, 0 turns them off (every path ray sweeps); frames are bit-identical either way.  Defaults 64 and 32; environment
  * TRT_PATHGRID="e,s" overrides the defaults.  Scenes with more than 256 spheres render without any candidate table. */
 int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_cells);
+/* Sub-families of the spheres (csrc/trt_raygrid.h).  "Every ray that starts anywhere on sphere i" is a fat family: in a dense
+ * scene (256 spheres) its direction cells list 6.5 candidates per path ray for 1.1 exact hits.  With m > 0 the surface of
+ * every sphere is cut into 6 m^2 patches (a cube map of the direction centre -> origin) and each patch -- and its mirror image
+ * in the ground -- gets its own family and table: apex under the middle of the patch, membership radius 0.82 / 0.52 / 0.44 /
+ * 0.33 of the sphere's for m = 1..4, hence narrower cones and shorter lists (3.6 candidates at m = 2) for 6 m^2 times the
+ * table memory (sphere_cells = 32, 256 spheres: 25 MB at m = 0, 604 MB at m = 2).  The membership of every ray in the family
+ * it is looked up in is still checked in FP64 per ray; frames are bit-identical for every m.  m = -1 (default): 2 for scenes of
+ * 128 spheres or more, else 0.  Environment TRT_PATHGRID="e,s,m" sets all three defaults. */
+int trt_set_path_patches(trt_context *ctx, int m);
+/* m and the patches per sphere (1, or 6 m^2) of the tables the current scene renders with; 0, 0 when the tables are off */
+int trt_get_path_patches(trt_context *ctx, int *m, int *patches_per_sphere);
+/* The family code of the production kernel for a path ray (trt_probe_rays_production): kind 0 = the ray starts at the eye,
+ * 1 = reflected by the ground, parent from the eye, 2 = the ray starts on `sphere`, 3 = reflected by the ground, its parent
+ * started on `sphere` at parent_origin (3 doubles: the patch of the sphere follows from it).  -1: no family. */
+int trt_path_family_code(trt_context *ctx, int kind, int sphere, const double *parent_origin);
 /* Scenes with fewer than `min_spheres` spheres keep the sweep for their path rays: below about a dozen spheres 9 VALU per
  * sphere are cheaper than a look-up with its membership test (default 12; 0 = tables for every scene). */
 int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres);
@@ -182,7 +197,8 @@ int trt_set_compaction(trt_context *ctx, int mode);
 int trt_render_variant(trt_context *ctx, int *decoupled, int *workgroup_threads);
 
 /* Copy the path rays' tables to the host (tests: the device-built lists must equal the host reference builder's): list
- * cells (2*6*eye_cells^2, then 2N*6*sphere_cells^2) and the pool of long lists, as built for `camera`'s eye.
+ * cells (2*6*eye_cells^2, then 2NP*6*sphere_cells^2 for P patches per sphere: patch k of sphere i at i P + k, then the mirror
+ * images in the same order) and the pool of long lists, as built for `camera`'s eye.
  * info: {enabled, eye_cells, sphere_cells, N, cells, pool words used by the scene's tables, by the eye's, pool capacity}.
  * Returns the number of cells copied, 0 when the tables are off, or a negative TRT_ERR_*. */
 long trt_read_path_tables(trt_context *ctx, const Camera *camera, unsigned long long *cells, size_t capacity_cells,
@@ -235,9 +251,10 @@ int trt_probe_rays(trt_context *ctx, const Ray *rays, size_t n, int *obj, double
 
 /* The same probe through the PRODUCTION kernel's stages (csrc/trt_rounds.hpp: candidate tables, fall-back sweep, exact
  * tests, surface record, lighting), so that trace_ray (TRT.c:793), ray_intersects_sphere/plane (:638, :677),
- * get_skybox_color (:700) and apply_lighting (:894) are each checked on the code that ships.  families[i] = the family of
- * the path-ray tables ray i is looked up in (0 eye, 1 mirror eye, 2 + s sphere s, 2 + N + s mirror sphere s; negative or
- * families == NULL: none, the ray's wave sweeps); a ray that is not a member of the family named falls back by itself.
+ * get_skybox_color (:700) and apply_lighting (:894) are each checked on the code that ships.  families[i] = the kernel's
+ * family code of ray i (trt_path_family_code: 0 eye, 1 mirror eye, 2 + s starts on sphere s, codes from 2 + N on: mirror image
+ * of a patch of a sphere; negative or families == NULL: none, the ray's wave sweeps); a ray that is not a member of the
+ * family named falls back by itself.
  * camera: its origin is the eye the tables of families 0 and 1 are built for. */
 int trt_probe_rays_production(trt_context *ctx, const Camera *camera, const Ray *rays, const int *families, size_t n, int *obj,
                               double *point, double *normal, double *material, double *lit);

@@ -37,6 +37,16 @@
 #ifndef TRT_PATHGRID_MIN_SPHERES
 #define TRT_PATHGRID_MIN_SPHERES 12
 #endif
+// Sub-families of the spheres (trt_raygrid.h): the surface of every sphere is cut into 6 m^2 patches with a family each.
+// -1: by the number of spheres (dense scenes pay for the larger tables with much shorter candidate lists), 0: one family
+// per sphere, 1..4: m.
+#ifndef TRT_PATHGRID_PATCHES
+#define TRT_PATHGRID_PATCHES -1
+#endif
+// TRT_PATHGRID_PATCHES = -1: scenes of at least this many spheres get m = 2 (24 patches per sphere)
+#ifndef TRT_PATCHES_FROM_SPHERES
+#define TRT_PATCHES_FROM_SPHERES 128
+#endif
 
 #include "trt_common.hpp"
 #include "trt_rounds.hpp"
@@ -129,11 +139,13 @@ struct trt_context
     // the tables as LIST CELLS (trt_raygrid.h), which is what the kernel reads: one 64-bit word per cell, long lists in d_pool
     DeviceBuffer<unsigned long long> d_dir_lists, d_point_lists, d_path_lists, d_pool;
     DeviceBuffer<unsigned int> d_pool_used;    // [0] words taken by the scene's tables, [16] by the eye's (a cache line apart)
-    DeviceBuffer<trt_rayfamily> d_families;    // the 2N families of the spheres, for the marking kernel
-    DeviceBuffer<double> d_sphere_fam;         // per sphere {mirror centre, r_chk}: what the render kernel keeps in LDS
+    DeviceBuffer<trt_rayfamily> d_families;    // the 2NP families of the spheres, for the marking kernel
+    DeviceBuffer<double> d_sphere_fam;         // per sphere {mirror centre, |r|}: what the render kernel keeps in LDS
+    DeviceBuffer<double> d_patch_rec;          // per patch {t, rho, mirrored t, rho}: likewise
     int path_g_eye = TRT_PATHGRID_EYE, path_g_sph = TRT_PATHGRID_SPHERE; // 0 = no path tables (every path ray sweeps)
     int path_min_spheres = TRT_PATHGRID_MIN_SPHERES;                      // scenes with fewer spheres sweep
-    int path_built_for[3] = {-1, -1, -1};
+    int path_patches = TRT_PATHGRID_PATCHES;                              // m of the spheres' sub-families; -1: by the number of spheres
+    int path_built_for[4] = {-1, -1, -1, -2};
     size_t pool_scene_words = 0, pool_eye_words = 0; // capacities of the two parts of d_pool
     trt_cull_scene cull_scene{};                      // of the spheres the tables were built from
     double eye_built[3] = {0.0, 0.0, 0.0}, ground_built[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -159,6 +171,7 @@ struct trt_context
     int rounds_blocks_per_cu = 0;
     int compact_blocks_per_cu = 0; // the same for the kernel with shading rings in LDS
     long last_units = 0;           // samples of the most recent launch (trt_render_variant / trt_kernel_info describe that launch's kernel)
+    bool last_compact = false;     // the most recent launch ran the kernel with the shading decoupled
     int compaction = -1;           // trt_set_compaction: -1 when it costs no occupancy, 0 never, 1 whenever the rings fit
     size_t occupancy_for_lds = (size_t)-1;
     hipEvent_t ev_chunk[16]; // hand-over of framebuffer chunks to the host copy threads (trt_render_host)
@@ -183,15 +196,21 @@ namespace
 
 constexpr int kCompactionMinLights = 2; // trt_set_compaction(-1): decouple the shading from two lights up (with one it is a wash)
 
-// LDS of render_rounds_kernel<.., false, true>: the image, then one shading ring per wave of the workgroup
-size_t compact_ring_at(const trt::SceneView &s, int spp)
+// LDS image of the production kernel for the context's scene and tables
+size_t image_lds_bytes(const trt_context *ctx, int spp)
 {
-    return (trt::rounds_lds_bytes(s, spp) / sizeof(double) + 1) & ~(size_t)1; // in doubles, on a 16-byte boundary
+    return trt::rounds_lds_bytes(ctx->scene, spp, ctx->grids.path_enabled ? ctx->grids.patch_count : 0);
 }
 
-size_t compact_lds_bytes(const trt::SceneView &s, int spp)
+// LDS of render_rounds_kernel<.., false, true>: the image, then one shading ring per wave of the workgroup
+size_t compact_ring_at(const trt_context *ctx, int spp)
 {
-    return sizeof(double) * (compact_ring_at(s, spp) + (size_t)(trt::kCompactBlock / 64) * trt::kRingDoubles);
+    return (image_lds_bytes(ctx, spp) / sizeof(double) + 1) & ~(size_t)1; // in doubles, on a 16-byte boundary
+}
+
+size_t compact_lds_bytes(const trt_context *ctx, int spp)
+{
+    return sizeof(double) * (compact_ring_at(ctx, spp) + (size_t)(trt::kCompactBlock / 64) * trt::kRingDoubles);
 }
 
 // Does a frame of `units` samples on this context run the kernel with the shading decoupled from the owning lane (COMPACT,
@@ -205,6 +224,8 @@ constexpr long kCompactionMinUnits = 16L << 20;
 static bool renders_decoupled(const trt_context *ctx, long units)
 {
     if (ctx->kernel != 0 || ctx->ior_count || ctx->compact_blocks_per_cu <= 0 || ctx->compaction == 0)
+        return false;
+    if (ctx->grids.path_enabled && ctx->grids.patch_m) // scenes whose spheres have patches (dense ones) run the plain rounds
         return false;
     const bool pays = ctx->scene.num_dir + ctx->scene.num_point >= kCompactionMinLights && units >= kCompactionMinUnits &&
                       ctx->compact_blocks_per_cu * trt::kCompactBlock >= ctx->rounds_blocks_per_cu * trt::kPersistentBlock;
@@ -423,48 +444,73 @@ int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
     return TRT_OK;
 }
 
-// Direction tables of the 2N sphere families of the path rays (trt_raygrid.h); the two families of the eye follow per camera
-// (ensure_eye_tables).  The host places the families (O(N)), the device forms the cones and marks and packs the cells.
+// m of the spheres' sub-families (trt_raygrid.h) for a scene of n spheres
+int patches_for(const trt_context *ctx, int n)
+{
+    if (ctx->path_patches >= 0)
+        return std::min(ctx->path_patches, TRT_PATCH_MAX_M);
+    return n >= TRT_PATCHES_FROM_SPHERES ? 2 : 0;
+}
+
+// Direction tables of the 2NP families of the spheres of the path rays (trt_raygrid.h: P patches per sphere and their mirror
+// images); the two families of the eye follow per camera (ensure_eye_tables).  The host places the families (O(NP)), the
+// device forms the cones and marks and packs the cells.
 int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const double *ground)
 {
     const int n = (int)(ctx->h_spheres.size() / 9);
     trt::GridView &g = ctx->grids;
     g.path_enabled = 0;
+    g.patch_m = g.patch_count = 0;
     ctx->eye_tables_valid = false;
     ctx->path_built_for[0] = ctx->path_g_eye;
     ctx->path_built_for[1] = ctx->path_g_sph;
     ctx->path_built_for[2] = ctx->path_min_spheres;
+    ctx->path_built_for[3] = ctx->path_patches;
     ctx->cull_scene = cs;
     memcpy(ctx->ground_built, ground, sizeof ctx->ground_built);
     const int ge = ctx->path_g_eye, gs = ctx->path_g_sph;
     if (ge < 2 || gs < 2 || n > TRT_LIST_MAX_SPHERES || n < ctx->path_min_spheres)
         return TRT_OK; // path_enabled = 0: every path ray sweeps
+    trt_patchset patches;
+    trt_patchset_init(&patches, patches_for(ctx, n));
+    const size_t P = (size_t)patches.count, families = 2 * (size_t)n * P;
     const size_t eye_cells = 6 * (size_t)ge * ge, sph_cells = 6 * (size_t)gs * gs;
-    HIP_TRY(ctx->d_path_lists.reserve(2 * eye_cells + 2 * (size_t)n * sph_cells));
-    HIP_TRY(ctx->d_families.reserve(2 * (size_t)std::max(n, 1)));
+    if (2 * eye_cells + families * sph_cells >= 0xffffffffull)
+        return fail(TRT_ERR_CAPACITY, "path tables of %zu families x %zu cells", families, sph_cells);
+    HIP_TRY(ctx->d_path_lists.reserve(2 * eye_cells + families * sph_cells)); // the eye's two tables first
+    HIP_TRY(ctx->d_families.reserve(std::max<size_t>(families, 1)));
     HIP_TRY(ctx->d_sphere_fam.reserve(4 * (size_t)std::max(n, 1)));
-    std::vector<trt_rayfamily> fam(2 * (size_t)std::max(n, 1));
-    std::vector<double> rec(4 * (size_t)std::max(n, 1));
-    trt_sphere_families(ctx->h_spheres.data(), n, ground, &cs, fam.data());
-    for (int i = 0; i < n; i++)
-    {
-        rec[4 * i + 0] = fam[n + i].a[0], rec[4 * i + 1] = fam[n + i].a[1], rec[4 * i + 2] = fam[n + i].a[2];
-        rec[4 * i + 3] = fam[i].r_chk;
-    }
+    HIP_TRY(ctx->d_patch_rec.reserve(P * TRT_PATCH_RECORD));
+    std::vector<trt_rayfamily> fam(std::max<size_t>(families, 1));
+    std::vector<double> rec(4 * (size_t)std::max(n, 1)), prec(P * TRT_PATCH_RECORD);
+    trt_family_consts consts;
+    trt_sphere_families(ctx->h_spheres.data(), n, ground, &cs, &patches, fam.data(), rec.data(), &consts);
+    trt_patch_records(&patches, ground, prec.data());
+    HIP_TRY(hipMemcpy(ctx->d_patch_rec.ptr, prec.data(), prec.size() * sizeof(double), hipMemcpyHostToDevice));
     if (n)
     {
-        HIP_TRY(hipMemcpy(ctx->d_families.ptr, fam.data(), 2 * (size_t)n * sizeof(trt_rayfamily), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_families.ptr, fam.data(), families * sizeof(trt_rayfamily), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->d_sphere_fam.ptr, rec.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((sph_cells + 255) / 256), (unsigned)(2 * n)), dim3(256), 0, ctx->stream,
-                           (const double *)ctx->d_spheres.ptr, n, (const trt_rayfamily *)ctx->d_families.ptr, trt_rayfamily{}, trt_rayfamily{}, 0, gs,
-                           ctx->d_path_lists.ptr + 2 * eye_cells, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words);
+        for (size_t first = 0; first < families; first += 32768) // grid.y is limited to 65535
+        {
+            const unsigned batch = (unsigned)std::min<size_t>(32768, families - first);
+            hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((sph_cells + 255) / 256), batch), dim3(256), 0, ctx->stream,
+                               (const double *)ctx->d_spheres.ptr, n, (const trt_rayfamily *)ctx->d_families.ptr + first, trt_rayfamily{}, trt_rayfamily{}, 0,
+                               gs, ctx->d_path_lists.ptr + 2 * eye_cells + first * sph_cells, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     g.path_lists = ctx->d_path_lists.ptr;
+    g.eye_at = 0;
+    g.sph_at = (unsigned)(2 * eye_cells);
     g.pool = ctx->d_pool.ptr;
     g.sphere_fam = ctx->d_sphere_fam.ptr;
-    g.rg2_sph = n ? fam[0].rg2 : 0.0;
+    g.patch_rec = ctx->d_patch_rec.ptr;
+    g.patch_m = patches.m;
+    g.patch_count = patches.count;
+    g.rg2_sph = consts.rg * consts.rg;
+    g.slack0 = consts.slack;
     g.g_eye = ge;
     g.g_sph = gs;
     g.path_enabled = 1;
@@ -477,7 +523,11 @@ int build_tables(trt_context *ctx, const trt_cull_scene &cs, const double *groun
 {
     const size_t n = ctx->h_spheres.size() / 9, nd = ctx->h_dir.size() / 6, np = ctx->h_point.size() / 7;
     const size_t gd = (size_t)ctx->dirgrid_cells, gp = (size_t)ctx->pointgrid_cells, ge = (size_t)ctx->path_g_eye, gs = (size_t)ctx->path_g_sph;
-    ctx->pool_scene_words = std::max<size_t>(1024, nd * gd * gd + np * 6 * gp * gp + 2 * n * 6 * gs * gs);
+    // one pool word per cell; the many small tables of sub-families (their lists are short: that is what they are for) get
+    // half a word per cell -- a list that finds no room leaves its cell TRT_LIST_NONE and its rays sweep
+    const int m = patches_for(ctx, (int)n);
+    const size_t sphere_cells = 2 * n * (m ? 6 * (size_t)m * m : 1) * 6 * gs * gs;
+    ctx->pool_scene_words = std::max<size_t>(1024, nd * gd * gd + np * 6 * gp * gp + (m ? sphere_cells / 2 : sphere_cells));
     ctx->pool_eye_words = std::max<size_t>(1024, 2 * 6 * ge * ge);
     if (ctx->pool_scene_words + ctx->pool_eye_words >= 0xffffffffull)
         return fail(TRT_ERR_CAPACITY, "candidate tables too large");
@@ -508,11 +558,36 @@ int ensure_eye_tables(trt_context *ctx, const Camera *camera, hipStream_t stream
     const size_t eye_cells = 6 * (size_t)ge * ge;
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->d_pool_used.ptr + 16), (int)ctx->pool_scene_words, 1, stream));
     hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((eye_cells + 255) / 256), 2u), dim3(256), 0, stream, (const double *)ctx->d_spheres.ptr, n,
-                       (const trt_rayfamily *)nullptr, g.eye[0], g.eye[1], 1, ge, ctx->d_path_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr + 16,
+                       (const trt_rayfamily *)nullptr, g.eye[0], g.eye[1], 1, ge, ctx->d_path_lists.ptr + g.eye_at, ctx->d_pool.ptr, ctx->d_pool_used.ptr + 16,
                        (unsigned)(ctx->pool_scene_words + ctx->pool_eye_words));
     HIP_TRY(hipGetLastError());
     memcpy(ctx->eye_built, eye, sizeof eye);
     ctx->eye_tables_valid = true;
+    return TRT_OK;
+}
+
+// The production kernel's occupancy depends on the scene and its tables only through the size of the LDS image: queried once
+// per size, not once per frame.
+int refresh_occupancy(trt_context *ctx)
+{
+    const trt::SceneView &v = ctx->scene;
+    const size_t lds_need = std::max(scene_lds_bytes(v), image_lds_bytes(ctx, 64));
+    if (lds_need > (size_t)ctx->lds_limit)
+        return fail(TRT_ERR_CAPACITY, "scene needs %zu B of LDS staging, device offers %d", lds_need, ctx->lds_limit);
+    if (ctx->occupancy_for_lds != image_lds_bytes(ctx, 64))
+    {
+        int blocks = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock, image_lds_bytes(ctx, 64)));
+        ctx->rounds_blocks_per_cu = std::max(blocks, 1);
+        ctx->occupancy_for_lds = image_lds_bytes(ctx, 64);
+        ctx->compact_blocks_per_cu = 0;
+        if (compact_lds_bytes(ctx, 64) <= (size_t)ctx->lds_limit)
+        {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false, false, true>, trt::kCompactBlock,
+                                                                 compact_lds_bytes(ctx, 64)));
+            ctx->compact_blocks_per_cu = blocks;
+        }
+    }
     return TRT_OK;
 }
 
@@ -558,7 +633,7 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
                       (!np || !memcmp(ctx->h_point.data(), hp, (size_t)np * sizeof(PointLight))) &&
                       ctx->grids_built_for[0] == ctx->dirgrid_cells && ctx->grids_built_for[1] == ctx->pointgrid_cells &&
                       ctx->path_built_for[0] == ctx->path_g_eye && ctx->path_built_for[1] == ctx->path_g_sph &&
-                      ctx->path_built_for[2] == ctx->path_min_spheres &&
+                      ctx->path_built_for[2] == ctx->path_min_spheres && ctx->path_built_for[3] == ctx->path_patches &&
                       !memcmp(ctx->ground_built, &scene->ground, sizeof ctx->ground_built);
     if (!same)
     {
@@ -581,25 +656,7 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
     v.num_dir = nd;
     v.num_point = np;
     memcpy(v.ground, &scene->ground, sizeof(Plane));
-    const size_t lds_need = std::max(scene_lds_bytes(v), trt::rounds_lds_bytes(v, 64));
-    if (lds_need > (size_t)ctx->lds_limit)
-        return fail(TRT_ERR_CAPACITY, "scene needs %zu B of LDS staging, device offers %d", lds_need, ctx->lds_limit);
-    if (ctx->occupancy_for_lds != trt::rounds_lds_bytes(v, 64))
-    { // occupancy depends on the scene only through the LDS image size: query once per size, not once per frame
-        int blocks = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock,
-                                                             trt::rounds_lds_bytes(v, 64)));
-        ctx->rounds_blocks_per_cu = std::max(blocks, 1);
-        ctx->occupancy_for_lds = trt::rounds_lds_bytes(v, 64);
-        ctx->compact_blocks_per_cu = 0;
-        if (compact_lds_bytes(v, 64) <= (size_t)ctx->lds_limit)
-        {
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false, false, true>, trt::kCompactBlock,
-                                                                 compact_lds_bytes(v, 64)));
-            ctx->compact_blocks_per_cu = blocks;
-        }
-    }
-    return TRT_OK;
+    return refresh_occupancy(ctx);
 }
 
 int prepare_jitter(trt_context *ctx, const Camera *cam, int width, int height, int spp)
@@ -713,9 +770,9 @@ static int init_context(trt_context *ctx)
     }
     if (const char *e = getenv("TRT_PATHGRID"))
     {
-        int ge = 0, gs = 0;
-        if (sscanf(e, "%d,%d", &ge, &gs) == 2 && ge >= 0 && gs >= 0 && ge <= 1024 && gs <= 256)
-            ctx->path_g_eye = ge, ctx->path_g_sph = gs;
+        int ge = 0, gs = 0, m = TRT_PATHGRID_PATCHES;
+        if (sscanf(e, "%d,%d,%d", &ge, &gs, &m) >= 2 && ge >= 0 && gs >= 0 && ge <= 1024 && gs <= 256 && m >= -1 && m <= TRT_PATCH_MAX_M)
+            ctx->path_g_eye = ge, ctx->path_g_sph = gs, ctx->path_patches = m;
     }
     if (const char *e = getenv("TRT_COMPACTION"))
     {
@@ -749,7 +806,12 @@ static int init_context(trt_context *ctx)
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
-    (void)hipFuncSetAttribute((const void *)trt::probe_rounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::probe_rounds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::probe_rounds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     return TRT_OK;
 }
 
@@ -795,6 +857,7 @@ extern "C" int trt_destroy(trt_context *ctx)
     ctx->d_dir_lists.release();
     ctx->d_point_lists.release();
     ctx->d_path_lists.release();
+    ctx->d_patch_rec.release();
     ctx->d_pool.release();
     ctx->d_pool_used.release();
     ctx->d_families.release();
@@ -921,7 +984,8 @@ extern "C" int trt_render_variant(trt_context *ctx, int *decoupled, int *workgro
 {
     if (!ctx)
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
-    const bool d = ctx->have_scene && renders_decoupled(ctx, ctx->last_units > 0 ? ctx->last_units : kCompactionMinUnits);
+    // the variant the most recent launch ran; before the first launch, what a whole large frame would run
+    const bool d = ctx->have_scene && (ctx->last_units > 0 ? ctx->last_compact : renders_decoupled(ctx, kCompactionMinUnits));
     if (decoupled)
         *decoupled = d ? 1 : 0;
     if (workgroup_threads)
@@ -967,7 +1031,8 @@ extern "C" int trt_set_light_grids(trt_context *ctx, int directional_cells, int 
     std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
     trt_cull_scene cs;
     trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
-    return build_tables(ctx, cs, ctx->scene.ground);
+    const int rc = build_tables(ctx, cs, ctx->scene.ground);
+    return rc ? rc : refresh_occupancy(ctx);
 }
 
 extern "C" int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_cells)
@@ -984,7 +1049,56 @@ extern "C" int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_ce
     std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
     trt_cull_scene cs;
     trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
-    return build_tables(ctx, cs, ctx->scene.ground);
+    const int rc = build_tables(ctx, cs, ctx->scene.ground);
+    return rc ? rc : refresh_occupancy(ctx);
+}
+
+extern "C" int trt_set_path_patches(trt_context *ctx, int m)
+{
+    if (!ctx || m < -1 || m > TRT_PATCH_MAX_M)
+        return fail(TRT_ERR_ARGUMENT, "patches %d", m);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still read the old tables
+    ctx->path_patches = m;
+    if (!ctx->have_scene)
+        return TRT_OK;
+    const int n = (int)(ctx->h_spheres.size() / 9);
+    std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
+    trt_cull_scene cs;
+    trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
+    const int rc = build_tables(ctx, cs, ctx->scene.ground);
+    return rc ? rc : refresh_occupancy(ctx);
+}
+
+extern "C" int trt_get_path_patches(trt_context *ctx, int *m, int *patches_per_sphere)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    if (m)
+        *m = ctx->grids.path_enabled ? ctx->grids.patch_m : 0;
+    if (patches_per_sphere)
+        *patches_per_sphere = ctx->grids.path_enabled ? ctx->grids.patch_count : 0;
+    return TRT_OK;
+}
+
+extern "C" int trt_path_family_code(trt_context *ctx, int kind, int sphere, const double *parent_origin)
+{
+    if (!ctx || !ctx->have_scene || !ctx->grids.path_enabled || kind < 0 || kind > 3)
+        return -1;
+    if (kind < 2)
+        return kind;
+    const int n = (int)(ctx->h_spheres.size() / 9);
+    if (sphere < 0 || sphere >= n)
+        return -1;
+    if (kind == 2)
+        return 2 + sphere;
+    if (!parent_origin)
+        return -1;
+    if (!ctx->grids.patch_m)
+        return 2 + n + sphere; // one family per sphere
+    const double *c = ctx->h_spheres.data() + 9 * (size_t)sphere;
+    const int k = trt_patch_of(ctx->grids.patch_m, parent_origin[0] - c[0], parent_origin[1] - c[1], parent_origin[2] - c[2]);
+    return 2 + n + ((sphere << TRT_PATCH_SHIFT) | k);
 }
 
 extern "C" int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres)
@@ -1000,7 +1114,8 @@ extern "C" int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres)
     std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
     trt_cull_scene cs;
     trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
-    return build_tables(ctx, cs, ctx->scene.ground);
+    const int rc = build_tables(ctx, cs, ctx->scene.ground);
+    return rc ? rc : refresh_occupancy(ctx);
 }
 
 extern "C" long trt_read_path_tables(trt_context *ctx, const Camera *camera, unsigned long long *cells, size_t capacity_cells,
@@ -1019,7 +1134,8 @@ extern "C" long trt_read_path_tables(trt_context *ctx, const Camera *camera, uns
     const int n = (int)(ctx->h_spheres.size() / 9);
     unsigned used[32] = {0};
     HIP_TRY(hipMemcpy(used, ctx->d_pool_used.ptr, sizeof used, hipMemcpyDeviceToHost));
-    const size_t total = g.path_enabled ? 2 * 6 * (size_t)g.g_eye * g.g_eye + 2 * (size_t)n * 6 * (size_t)g.g_sph * g.g_sph : 0;
+    const size_t eye_total = 2 * 6 * (size_t)g.g_eye * g.g_eye, sph_total = 2 * (size_t)n * (size_t)g.patch_count * 6 * (size_t)g.g_sph * g.g_sph;
+    const size_t total = g.path_enabled ? eye_total + sph_total : 0;
     const size_t pool_words = ctx->pool_scene_words + ctx->pool_eye_words;
     info[0] = g.path_enabled, info[1] = g.g_eye, info[2] = g.g_sph, info[3] = n, info[4] = (long)total;
     info[5] = (long)used[0], info[6] = (long)used[16] - (long)ctx->pool_scene_words, info[7] = (long)pool_words;
@@ -1027,7 +1143,9 @@ extern "C" long trt_read_path_tables(trt_context *ctx, const Camera *camera, uns
         return 0;
     if (capacity_cells < total || capacity_pool < pool_words)
         return fail(TRT_ERR_CAPACITY, "tables have %zu cells and %zu pool words", total, pool_words);
-    HIP_TRY(hipMemcpy(cells, ctx->d_path_lists.ptr, total * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cells, ctx->d_path_lists.ptr + g.eye_at, eye_total * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (sph_total)
+        HIP_TRY(hipMemcpy(cells + eye_total, ctx->d_path_lists.ptr + g.sph_at, sph_total * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pool, ctx->d_pool.ptr, pool_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return (long)total;
 }
@@ -1186,11 +1304,11 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         // shading decoupled from the owning lane (COMPACT, trt_rounds.hpp) when the rings fit in LDS: by default only if they
         // cost no resident wave and the scene has lights enough to pay for them.
         // (the occupancy figures were taken for 64 rays per pixel: with more, the jitter table may push the rings out of LDS)
-        const bool compact = renders_decoupled(ctx, units) && compact_lds_bytes(ctx->scene, rays_per_pixel) <= (size_t)ctx->lds_limit;
+        const bool compact = renders_decoupled(ctx, units) && compact_lds_bytes(ctx, rays_per_pixel) <= (size_t)ctx->lds_limit;
         ctx->last_units = units;
-        if (trt::rounds_lds_bytes(ctx->scene, rays_per_pixel) > (size_t)ctx->lds_limit)
+        if (image_lds_bytes(ctx, rays_per_pixel) > (size_t)ctx->lds_limit)
             return fail(TRT_ERR_CAPACITY, "scene and %d rays per pixel need %zu B of LDS staging, device offers %d", rays_per_pixel,
-                        trt::rounds_lds_bytes(ctx->scene, rays_per_pixel), ctx->lds_limit);
+                        image_lds_bytes(ctx, rays_per_pixel), ctx->lds_limit);
         trt::PersistentLaunch pl = trt::persistent_launch_shape(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0),
                                                                 ctx->rounds_blocks_per_cu, units);
         if (compact)
@@ -1199,28 +1317,38 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
             const long want = (units + trt::kCompactBlock - 1) / trt::kCompactBlock;
             pl = trt::PersistentLaunch{(unsigned)std::max(1L, std::min(want, cap)), (unsigned)trt::kCompactBlock};
         }
-        const size_t plds = trt::rounds_lds_bytes(ctx->scene, rays_per_pixel);
+        const size_t plds = image_lds_bytes(ctx, rays_per_pixel);
         const dim3 grid(pl.grid), block(pl.block);
+        if (ctx->ior_count && ctx->ior_count != ctx->scene.num_spheres) // before the first event of the launch is recorded
+            return fail(TRT_ERR_ARGUMENT, "trt_set_refraction was given %d indices, the scene has %d spheres", ctx->ior_count, ctx->scene.num_spheres);
+        ctx->last_compact = compact;
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
+        const bool patches = ctx->grids.path_enabled && ctx->grids.patch_m > 0; // a family per patch of a sphere: its own instantiations
         if (ctx->ior_count)
         { // the refraction extension (parity unpinned): its own instantiation, the reference's path is not touched
-            if (ctx->ior_count != ctx->scene.num_spheres)
-                return fail(TRT_ERR_ARGUMENT, "trt_set_refraction was given %d indices, the scene has %d spheres", ctx->ior_count, ctx->scene.num_spheres);
             f.ior = ctx->d_ior.ptr;
-            if (ctx->counters_enabled)
+            if (patches && ctx->counters_enabled)
+                hipLaunchKernelGGL((trt::render_rounds_kernel<true, true, false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
+            else if (patches)
+                hipLaunchKernelGGL((trt::render_rounds_kernel<false, true, false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
+            else if (ctx->counters_enabled)
                 hipLaunchKernelGGL((trt::render_rounds_kernel<true, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
             else
                 hipLaunchKernelGGL((trt::render_rounds_kernel<false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         }
         else if (compact)
         {
-            f.ring_at = (unsigned)compact_ring_at(ctx->scene, rays_per_pixel);
-            const size_t clds = compact_lds_bytes(ctx->scene, rays_per_pixel);
+            f.ring_at = (unsigned)compact_ring_at(ctx, rays_per_pixel);
+            const size_t clds = compact_lds_bytes(ctx, rays_per_pixel);
             if (ctx->counters_enabled)
                 hipLaunchKernelGGL((trt::render_rounds_kernel<true, false, true>), grid, block, clds, stream, ctx->scene, ctx->cull, f, ctx->grids);
             else
                 hipLaunchKernelGGL((trt::render_rounds_kernel<false, false, true>), grid, block, clds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         }
+        else if (patches && ctx->counters_enabled)
+            hipLaunchKernelGGL((trt::render_rounds_kernel<true, false, false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
+        else if (patches)
+            hipLaunchKernelGGL((trt::render_rounds_kernel<false, false, false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         else if (ctx->counters_enabled)
             hipLaunchKernelGGL((trt::render_rounds_kernel<true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         else
@@ -1435,9 +1563,11 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
     if (!ctx)
         return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
-    const bool decoupled = ctx->have_scene && renders_decoupled(ctx, ctx->last_units > 0 ? ctx->last_units : kCompactionMinUnits);
+    const bool decoupled = ctx->have_scene && (ctx->last_units > 0 ? ctx->last_compact : renders_decoupled(ctx, kCompactionMinUnits));
+    const bool patches = ctx->have_scene && ctx->grids.path_enabled && ctx->grids.patch_m > 0;
     const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel
                      : decoupled      ? (const void *)trt::render_rounds_kernel<false, false, true>
+                     : patches        ? (const void *)trt::render_rounds_kernel<false, false, false, true>
                                       : (const void *)trt::render_rounds_kernel<false>;
     hipFuncAttributes attr;
     HIP_TRY(hipFuncGetAttributes(&attr, fn));
@@ -1450,7 +1580,7 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
     if (max_blocks_per_cu)
     {
         int blocks = 0;
-        const size_t lds = ctx->have_scene ? (ctx->kernel == 1 ? scene_lds_bytes(ctx->scene) : trt::rounds_lds_bytes(ctx->scene, 64)) : 0;
+        const size_t lds = ctx->have_scene ? (ctx->kernel == 1 ? scene_lds_bytes(ctx->scene) : image_lds_bytes(ctx, 64)) : 0;
         if (ctx->kernel == 1)
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_simple_kernel, 256, lds));
         else if (decoupled)
@@ -1559,9 +1689,14 @@ extern "C" int trt_probe_rays_production(trt_context *ctx, const Camera *camera,
     trt::FrameView f{};
     memcpy(f.cam, camera, sizeof(Camera));
     f.jitter = ctx->d_jitter.ptr; // spp = 0: nothing is read through it
-    hipLaunchKernelGGL(trt::probe_rounds_kernel, dim3((unsigned)((n + trt::kPersistentBlock - 1) / trt::kPersistentBlock)), dim3(trt::kPersistentBlock),
-                       trt::rounds_lds_bytes(ctx->scene, 0), ctx->stream, ctx->scene, ctx->cull, f, ctx->grids, (const double *)dr,
-                       families ? (const int *)(dobj.ptr + n) : (const int *)nullptr, (long)n, dobj.ptr, dp, dn, dm, dl);
+    if (ctx->grids.path_enabled && ctx->grids.patch_m > 0)
+        hipLaunchKernelGGL(trt::probe_rounds_kernel<true>, dim3((unsigned)((n + trt::kPersistentBlock - 1) / trt::kPersistentBlock)), dim3(trt::kPersistentBlock),
+                           image_lds_bytes(ctx, 0), ctx->stream, ctx->scene, ctx->cull, f, ctx->grids, (const double *)dr,
+                           families ? (const int *)(dobj.ptr + n) : (const int *)nullptr, (long)n, dobj.ptr, dp, dn, dm, dl);
+    else
+        hipLaunchKernelGGL(trt::probe_rounds_kernel<false>, dim3((unsigned)((n + trt::kPersistentBlock - 1) / trt::kPersistentBlock)), dim3(trt::kPersistentBlock),
+                           image_lds_bytes(ctx, 0), ctx->stream, ctx->scene, ctx->cull, f, ctx->grids, (const double *)dr,
+                           families ? (const int *)(dobj.ptr + n) : (const int *)nullptr, (long)n, dobj.ptr, dp, dn, dm, dl);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(obj, dobj.ptr, n * sizeof(int), hipMemcpyDeviceToHost));

@@ -103,42 +103,6 @@ static inline void trt_eye_families(const double eye[3], const double *ground /*
     }
 }
 
-/* The 2n families of the spheres: fam[i] = rays starting on sphere i, fam[n + i] = their reflections by the ground (apex = the
- * mirror image of the centre, membership radius TRT_FAMILY_SLACK larger).  All share one admissible range.  What the
- * kernel keeps per sphere is {mirror apex (3), r_chk of fam[i]}: it forms r_chk of fam[n + i] as r_chk + TRT_FAMILY_SLACK. */
-static inline void trt_sphere_families(const double *spheres, int n, const double *ground, const trt_cull_scene *cs, trt_rayfamily *fam)
-{
-    const double reach = (double)cs->cn + (double)cs->rm;
-    const double mag = __builtin_fabs(cs->c0[0]) + __builtin_fabs(cs->c0[1]) + __builtin_fabs(cs->c0[2]) + reach + 1.0;
-    double away = reach;
-    for (int i = 0; i < n; i++)
-    {
-        double m[3];
-        trt_mirror_point(spheres + 9 * i, ground, ground + 3, m);
-        const double lc[3] = {m[0] - cs->c0[0], m[1] - cs->c0[1], m[2] - cs->c0[2]};
-        const double far = __builtin_sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]);
-        away = far > away ? far : away; /* NaN (a ground without a normal) leaves it alone; such tables never pass the membership test */
-    }
-    const double rg = TRT_LIGHTGRID_RANGE * (reach + away) + 1.0;
-    for (int i = 0; i < n; i++)
-    {
-        double m[3];
-        trt_mirror_point(spheres + 9 * i, ground, ground + 3, m);
-        const double r_chk = __builtin_fabs(spheres[9 * i + 3]) * (1.0 + 1e-6) + TRT_FAMILY_SLACK + 1e-9 * mag;
-        trt_rayfamily_set(&fam[i], spheres + 9 * i, r_chk, rg);
-        trt_rayfamily_set(&fam[n + i], m, r_chk + TRT_FAMILY_SLACK, rg);
-    }
-}
-
-/* does the ray (o, d), d a unit vector up to 2^-40, belong to the family?  false for NaN */
-TRT_HD int trt_rayfamily_member(const trt_rayfamily *F, double ox, double oy, double oz, double dx, double dy, double dz)
-{
-    const double wx = ox - F->a[0], wy = oy - F->a[1], wz = oz - F->a[2];
-    const double cx = wy * dz - wz * dy, cy = wz * dx - wx * dz, cz = wx * dy - wy * dx;
-    const double c2 = cx * cx + cy * cy + cz * cz, lam = wx * dx + wy * dy + wz * dz, w2 = wx * wx + wy * wy + wz * wz;
-    return c2 <= F->r_chk2 && lam >= -F->r_chk && w2 <= F->rg2;
-}
-
 /* cell of direction (x, y, z) (any length > 0) in a cube map of 6 x g x g cells: the look-up of trt_pointgrid_cell */
 TRT_HD int trt_cubemap_cell(float x, float y, float z, float half_g, float g_max, int g)
 {
@@ -161,6 +125,198 @@ TRT_HD int trt_cubemap_cell(float x, float y, float z, float half_g, float g_max
     cu = __builtin_fminf(__builtin_fmaxf(cu, 0.0f), g_max);
     cv = __builtin_fminf(__builtin_fmaxf(cv, 0.0f), g_max);
     return (face * g + (int)cv) * g + (int)cu;
+}
+
+/* ---- SUB-FAMILIES of a sphere ("patches") --------------------------------------------------------------------------
+ * "Every ray that starts anywhere on sphere i" is a fat family: its members pass within r_i of the centre, so a direction
+ * cell holds every sphere within r_i + r_j of the line through the centre -- 6.5 candidates per path ray for 1.1 exact
+ * hits in a dense scene (256 spheres).  The ORIGIN of such a ray is known, though: the surface of sphere i is cut into
+ * P = 6 m^2 patches by a cube map of the direction centre -> origin (m cells per face side), and every patch k gets its own
+ * pair of families: apex  c_i + |r_i| t_k  (t_k inside the unit ball, under the middle of the patch), membership radius
+ * |r_i| rho_k + slack with rho_k = the largest distance from t_k to a point of the patch on the unit sphere (0.82 for m = 1,
+ * 0.51 for m = 2, 0.36 for m = 3, 0.28 for m = 4 instead of 1).  A ray that starts on patch k has its origin, hence its line,
+ * within that radius of the apex: it is a member -- and trt_rayfamily_member() still checks that for every ray, so a ray
+ * looked up in the wrong patch (the FP32 choice of the patch near a patch's edge, a degenerate normal) falls back to the sweep
+ * like any other non-member; nothing is taken on trust.  The mirror family of a patch (reflections by the ground of rays that
+ * started on it) has the mirror image of that apex.  m = 0: one family per sphere (t = 0, rho = 1), the tables of round 2.
+ * A path ray's family code with patches: 0 eye, 1 mirror eye, 2 + i: it starts on sphere i (the patch follows from its origin),
+ * 2 + n + (i << TRT_PATCH_SHIFT | k): reflected by the ground, parent started on patch k of sphere i; < 0: none.  Without
+ * (m = 0): 0, 1, 2 + i, 2 + n + i.
+ * Tables: 2 of the eye, then n P of the patches (sphere-major), then n P of their mirror images. */
+#define TRT_PATCH_MAX_M 4
+#define TRT_PATCH_MAX (6 * TRT_PATCH_MAX_M * TRT_PATCH_MAX_M)
+#define TRT_PATCH_SHIFT 7
+#define TRT_PATCH_RECORD 8 /* doubles per patch in the kernel's copy: t (3), rho | mirrored t (3), rho */
+
+typedef struct
+{
+    int m;     /* cells per face side of the origin's cube map; 0: one family per sphere */
+    int count; /* P: 1, or 6 m^2 */
+    double rec[TRT_PATCH_MAX][4]; /* per patch: apex offset t in units of the radius (3), membership radius rho in units of the radius */
+} trt_patchset;
+
+/* direction (u, v, 1) of a cube-map face in world axes: the frame of trt_cubemap_cell / trt_pointgrid_reaches */
+static inline void trt_face_direction(int face, double u, double v, double out[3])
+{
+    const int k = face >> 1;
+    out[k] = (face & 1) ? -1.0 : 1.0;
+    out[(k + 1) % 3] = u;
+    out[(k + 2) % 3] = v;
+}
+
+static inline void trt_patchset_init(trt_patchset *P, int m)
+{
+    if (m < 0)
+        m = 0;
+    if (m > TRT_PATCH_MAX_M)
+        m = TRT_PATCH_MAX_M;
+    P->m = m;
+    P->count = m ? 6 * m * m : 1;
+    for (int k = 0; k < TRT_PATCH_MAX; k++)
+        P->rec[k][0] = P->rec[k][1] = P->rec[k][2] = 0.0, P->rec[k][3] = 1.0 + 1e-6;
+    if (!m)
+        return; /* the whole sphere: apex = the centre, radius r (1 + 1e-6) */
+    const double step = 2.0 / (double)m;
+    for (int face = 0; face < 6; face++)
+        for (int j = 0; j < m; j++)
+            for (int c = 0; c < m; c++)
+            {
+                /* the patch grown by 0.02 cell, and past the face's edge where the look-up clamps: its FP32 choice of the
+                 * cell is off by <= 1e-6, and near a cube edge either face may be chosen */
+                const double u0 = c == 0 ? -1.001 : -1.0 + ((double)c - 0.02) * step, u1 = c == m - 1 ? 1.001 : -1.0 + ((double)c + 1.02) * step;
+                const double v0 = j == 0 ? -1.001 : -1.0 + ((double)j - 0.02) * step, v1 = j == m - 1 ? 1.001 : -1.0 + ((double)j + 1.02) * step;
+                const double cu[4] = {u0, u1, u1, u0}, cv[4] = {v0, v0, v1, v1};
+                double corner[4][3], mid[3] = {0.0, 0.0, 0.0};
+                for (int q = 0; q < 4; q++)
+                {
+                    trt_face_direction(face, cu[q], cv[q], corner[q]);
+                    const double len = __builtin_sqrt(corner[q][0] * corner[q][0] + corner[q][1] * corner[q][1] + corner[q][2] * corner[q][2]);
+                    for (int a = 0; a < 3; a++)
+                        corner[q][a] /= len, mid[a] += corner[q][a];
+                }
+                /* apex offset: centre of the smallest ball round the four corners (Badoiu-Clarkson: step towards the farthest
+                 * corner, 1/(i+1) of the way).  A ball round a point t inside the unit ball cuts a cap out of the unit sphere, and
+                 * a cap (smaller than a hemisphere) that holds the corners of a convex spherical quadrilateral holds all of it.
+                 * Whatever the iteration arrives at is valid: rho below is measured from it. */
+                double *rec = P->rec[(face * m + j) * m + c];
+                for (int a = 0; a < 3; a++)
+                    rec[a] = 0.25 * mid[a];
+                for (int it = 1; it <= 4096; it++)
+                {
+                    int far_q = 0;
+                    double far_d2 = -1.0;
+                    for (int q = 0; q < 4; q++)
+                    {
+                        const double e[3] = {corner[q][0] - rec[0], corner[q][1] - rec[1], corner[q][2] - rec[2]};
+                        const double d2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+                        if (d2 > far_d2)
+                            far_d2 = d2, far_q = q;
+                    }
+                    for (int a = 0; a < 3; a++)
+                        rec[a] += (corner[far_q][a] - rec[a]) / (double)(it + 1);
+                }
+                double far2 = 0.0;
+                for (int q = 0; q < 4; q++)
+                {
+                    const double e[3] = {corner[q][0] - rec[0], corner[q][1] - rec[1], corner[q][2] - rec[2]};
+                    const double d2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+                    far2 = d2 > far2 ? d2 : far2;
+                }
+                rec[3] = __builtin_sqrt(far2) * (1.0 + 1e-6) + 1e-9;
+            }
+}
+
+/* patch of the origin o of a ray that starts on the sphere with centre c: the look-up of trt_cubemap_cell on o - c */
+TRT_HD int trt_patch_of(int m, double wx, double wy, double wz)
+{
+    return m ? trt_cubemap_cell((float)wx, (float)wy, (float)wz, 0.5f * (float)m, (float)(m - 1), m) : 0;
+}
+
+/* what every family of the spheres shares: the admissible range and the slack of the membership radius */
+typedef struct
+{
+    double rg;    /* admissible |o - apex| */
+    double slack; /* membership radius of a patch's family = |r| rho + slack; TRT_FAMILY_SLACK more for its mirror image */
+} trt_family_consts;
+
+/* apex and membership radius of patch k of a sphere (centre c or, mirrored, its mirror image; t the patch's offset or its
+ * mirror image): the SAME two expressions in the kernel's look-up (path_cell) and in the builders */
+#define TRT_PATCH_APEX(c, r_abs, t) ((c) + (r_abs) * (t))
+#define TRT_PATCH_RCHK(r_abs, rho, slack) ((r_abs) * (rho) + (slack))
+
+/* mirror image of a DIRECTION (or offset) in the plane with normal nrm: t - 2 (t.nrm / nrm.nrm) nrm */
+static inline void trt_mirror_offset(const double t[3], const double nrm[3], double out[3])
+{
+    const double zero[3] = {0.0, 0.0, 0.0};
+    trt_mirror_point(t, zero, nrm, out);
+}
+
+/* The kernel's copy of the patches: per patch {t (3), rho, mirrored t (3), rho}. */
+static inline void trt_patch_records(const trt_patchset *P, const double *ground, double *out /* [P->count * TRT_PATCH_RECORD] */)
+{
+    for (int k = 0; k < P->count; k++)
+    {
+        double tm[3];
+        trt_mirror_offset(P->rec[k], ground + 3, tm);
+        double *o = out + (size_t)k * TRT_PATCH_RECORD;
+        o[0] = P->rec[k][0], o[1] = P->rec[k][1], o[2] = P->rec[k][2], o[3] = P->rec[k][3];
+        o[4] = tm[0], o[5] = tm[1], o[6] = tm[2], o[7] = P->rec[k][3];
+    }
+}
+
+/* The 2 n P families of the spheres: fam[i P + k] = rays starting on patch k of sphere i, fam[n P + i P + k] = their
+ * reflections by the ground (apex = the mirror image of the centre + |r| x the mirrored offset, membership radius
+ * TRT_FAMILY_SLACK larger).  All share one admissible range.  `centres` receives what the kernel keeps per sphere beside the
+ * sphere itself: {mirror image of the centre (3), w} with w = the membership radius of the sphere's family when there is one
+ * family per sphere (P->m == 0; the kernel adds TRT_FAMILY_SLACK for the mirror family) and |r| when there are patches. */
+static inline void trt_sphere_families(const double *spheres, int n, const double *ground, const trt_cull_scene *cs, const trt_patchset *P,
+                                       trt_rayfamily *fam, double *centres, trt_family_consts *consts)
+{
+    const double reach = (double)cs->cn + (double)cs->rm;
+    const double mag = __builtin_fabs(cs->c0[0]) + __builtin_fabs(cs->c0[1]) + __builtin_fabs(cs->c0[2]) + reach + 1.0;
+    double away = reach;
+    for (int i = 0; i < n; i++)
+    {
+        double m[3];
+        trt_mirror_point(spheres + 9 * i, ground, ground + 3, m);
+        const double lc[3] = {m[0] - cs->c0[0], m[1] - cs->c0[1], m[2] - cs->c0[2]};
+        const double far = __builtin_sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]);
+        away = far > away ? far : away; /* NaN (a ground without a normal) leaves it alone; such tables never pass the membership test */
+    }
+    const double rg = TRT_LIGHTGRID_RANGE * (reach + away) + 1.0;
+    consts->rg = rg;
+    consts->slack = TRT_FAMILY_SLACK + 1e-9 * mag;
+    const int count = P->count;
+    for (int i = 0; i < n; i++)
+    {
+        const double *c = spheres + 9 * i;
+        const double r_abs = __builtin_fabs(c[3]);
+        double m[3];
+        trt_mirror_point(c, ground, ground + 3, m);
+        if (centres)
+            centres[4 * i + 0] = m[0], centres[4 * i + 1] = m[1], centres[4 * i + 2] = m[2],
+                            centres[4 * i + 3] = P->m ? r_abs : TRT_PATCH_RCHK(r_abs, P->rec[0][3], consts->slack);
+        for (int k = 0; k < count; k++)
+        {
+            const double *t = P->rec[k];
+            double tm[3];
+            trt_mirror_offset(t, ground + 3, tm);
+            const double a[3] = {TRT_PATCH_APEX(c[0], r_abs, t[0]), TRT_PATCH_APEX(c[1], r_abs, t[1]), TRT_PATCH_APEX(c[2], r_abs, t[2])};
+            const double am[3] = {TRT_PATCH_APEX(m[0], r_abs, tm[0]), TRT_PATCH_APEX(m[1], r_abs, tm[1]), TRT_PATCH_APEX(m[2], r_abs, tm[2])};
+            const double r_chk = TRT_PATCH_RCHK(r_abs, t[3], consts->slack);
+            trt_rayfamily_set(&fam[(size_t)i * count + k], a, r_chk, rg);
+            trt_rayfamily_set(&fam[((size_t)n + i) * count + k], am, r_chk + TRT_FAMILY_SLACK, rg);
+        }
+    }
+}
+
+/* does the ray (o, d), d a unit vector up to 2^-40, belong to the family?  false for NaN */
+TRT_HD int trt_rayfamily_member(const trt_rayfamily *F, double ox, double oy, double oz, double dx, double dy, double dz)
+{
+    const double wx = ox - F->a[0], wy = oy - F->a[1], wz = oz - F->a[2];
+    const double cx = wy * dz - wz * dy, cy = wz * dx - wx * dz, cz = wx * dy - wy * dx;
+    const double c2 = cx * cx + cy * cy + cz * cz, lam = wx * dx + wy * dy + wz * dz, w2 = wx * wx + wy * wy + wz * wz;
+    return c2 <= F->r_chk2 && lam >= -F->r_chk && w2 <= F->rg2;
 }
 
 /* The cone of directions, seen from the family's apex, in which a member ray can hit sphere `s` (9-double record). */

@@ -54,13 +54,18 @@ struct GridView
     int enabled;
     int list_bits; // bits per entry of every list cell: 8, or 16 for scenes of more than 256 spheres (light tables only)
     // direction tables of the path rays' families (trt_raygrid.h): families 0 (eye) and 1 (mirror eye) have 6*g_eye^2 cells
-    // each, then 2N families (sphere i, then mirror sphere i) of 6*g_sph^2 cells
+    // each, from cell eye_at of path_lists (they change with the camera), then 2NP families (patch k of sphere i at i P + k, then
+    // their mirror images) of 6*g_sph^2 cells, from cell sph_at (they change with the scene only)
     int path_enabled;
     int g_eye, g_sph;
+    int patch_m, patch_count; // cells per face side of the origin's cube map (0: one family per sphere), P
+    unsigned eye_at, sph_at;
     const unsigned long long *path_lists;
     const unsigned long long *pool;
-    const double *sphere_fam; // per sphere: mirror image of the centre (3), r_chk of the sphere's family
-    double rg2_sph;           // admissible |o - apex|^2 of the 2N sphere families
+    const double *sphere_fam; // per sphere: mirror image of the centre (3), then r_chk of the sphere's family (patch_m == 0) or |r|
+    const double *patch_rec;  // per patch: t (3), rho | mirrored t (3), rho (TRT_PATCH_RECORD doubles)
+    double rg2_sph;           // admissible |o - apex|^2 of the families of the spheres
+    double slack0;            // membership radius of a patch's family = |r| rho + slack0 (TRT_FAMILY_SLACK more for its mirror image)
     trt_rayfamily eye[2];     // families 0 and 1, by value: they change with the camera
 };
 
@@ -81,22 +86,23 @@ struct LdsImage
     const double *jit;   // jitter x[spp], y[spp]
     const trt_dirgrid *dirgrid;     // headers of the light-space tables (trt_lightgrid.h), per directional light
     const trt_pointgrid *pointgrid; // per point light
-    const double *fam;              // per sphere: mirror image of the centre (3), r_chk of the sphere's family (trt_raygrid.h)
+    const double *fam;              // per sphere: mirror image of the centre (3), r_chk of its family or, with patches, |r| (trt_raygrid.h)
     const double *eye;              // the two families of the eye: 2 x {apex (3), r_chk, r_chk^2, rg^2}
+    const double *patch;            // per patch of a sphere's surface: t (3), rho | mirrored t (3), rho
 };
 
 // LDS image of a workgroup: culling table {Cx,Cy,Cz,kk} (4 floats per sphere, 16-B aligned, first) | per sphere {cx,cy,cz,r^2} |
 // mat[(n+2)*5] (spheres, ground even, ground odd) | dir lights: unit to-light(3) colour(3) | point lights: pos(3) colour(3)
 // intensity | byte/255.0 [256] | camera | jitter x[spp] y[spp] | one fixed-direction culling table per directional
-// light | headers of the light-space tables | per sphere {mirror centre, r_chk} of the path-ray families.
-// rounds_lds_bytes and stage_lds_image must agree.
-inline size_t rounds_lds_bytes(const SceneView &s, int spp)
+// light | headers of the light-space tables | per sphere {mirror centre, |r|} of the path-ray families | the two families
+// of the eye | the patches of a sphere's surface (`patches` records).  rounds_lds_bytes and stage_lds_image must agree.
+inline size_t rounds_lds_bytes(const SceneView &s, int spp, int patches)
 {
     const size_t padded = ((size_t)s.num_spheres + kCullGroup - 1) / kCullGroup * kCullGroup;
     return sizeof(double) * (padded * 2 + (size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * 6 +
                              (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp + 1 /* 16-B alignment */ +
                              (size_t)s.num_dir * padded * 2 + (size_t)s.num_dir * kDirGridDoubles + (size_t)s.num_point * kPointGridDoubles +
-                             (size_t)s.num_spheres * 4 + 2 * TRT_RAYFAMILY_DOUBLES);
+                             (size_t)s.num_spheres * 4 + 2 * TRT_RAYFAMILY_DOUBLES + (size_t)patches * TRT_PATCH_RECORD);
 }
 
 TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView &cull, const FrameView &f, const GridView &grids)
@@ -157,17 +163,19 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
         for (int i = threadIdx.x; i < np * kPointGridDoubles; i += blockDim.x)
             l_pointgrid[i] = ((const double *)grids.point)[i];
     }
-    double *l_fam = l_pointgrid + np * kPointGridDoubles, *l_eye = l_fam + 4 * n;
+    double *l_fam = l_pointgrid + np * kPointGridDoubles, *l_eye = l_fam + 4 * n, *l_patch = l_eye + 2 * TRT_RAYFAMILY_DOUBLES;
     if (grids.path_enabled)
     {
         for (int i = threadIdx.x; i < n * 4; i += blockDim.x)
             l_fam[i] = grids.sphere_fam[i];
         for (int i = threadIdx.x; i < 2 * TRT_RAYFAMILY_DOUBLES; i += blockDim.x)
             l_eye[i] = ((const double *)grids.eye)[i];
+        for (int i = threadIdx.x; i < grids.patch_count * TRT_PATCH_RECORD; i += blockDim.x)
+            l_patch[i] = grids.patch_rec[i];
     }
     __syncthreads();
     return LdsImage{l_cull, l_cull_dir, l_sph, l_mat, l_dir, l_pt, l_255, l_cam, l_jit,
-                    (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid, l_fam, l_eye};
+                    (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid, l_fam, l_eye, l_patch};
 }
 
 struct Hit
@@ -412,17 +420,17 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     return best;
 }
 
-// The list cell of a PATH ray (trt_raygrid.h).  `fam`: the family the ray is expected in (0 eye, 1 mirror eye, 2 + i sphere
-// i, 2 + n + i mirror sphere i, < 0 none).  `fallback` is set for an active lane whose ray fails the family's membership
-// test (its line must pass within r_chk of the apex, its origin not more than r_chk behind it, within the table's range; a
-// unit direction) or whose cell has no list: the caller then sweeps.
+// The list cell of a PATH ray (trt_raygrid.h), ONE FAMILY PER SPHERE (GridView::patch_m == 0).  `fam`: the family the ray is
+// expected in (0 eye, 1 mirror eye, 2 + i sphere i, 2 + n + i mirror sphere i, < 0 none).  `fallback` is set for an active lane
+// whose ray fails the family's membership test (its line must pass within r_chk of the apex, its origin not more than r_chk
+// behind it, within the table's range; a unit direction) or whose cell has no list: the caller then sweeps.
 TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n, int fam, d3 o, d3 d, bool active, bool &fallback)
 {
     const bool has = active && fam >= 0;
     const int f = has ? fam : 0;
     const int s = f >= 2 ? f - 2 : 0, i = s >= n ? s - n : s; // sphere of the family
     const bool of_eye = f < 2, mirrored = s >= n;
-    const double *rec = L.fam + 4 * i;
+    const double *rec = L.fam + 4 * i; // mirror image of the centre, r_chk of the sphere's family
     d3 apex = mirrored ? load3(rec) : load3(L.sph + 4 * i);
     double r_chk = mirrored ? rec[3] + TRT_FAMILY_SLACK : rec[3];
     const double *E = L.eye + TRT_RAYFAMILY_DOUBLES * (f & 1);
@@ -442,7 +450,63 @@ TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n
     const int g = of_eye ? G.g_eye : G.g_sph;
     const int at = trt_cubemap_cell((float)d.x, (float)d.y, (float)d.z, 0.5f * (float)g, (float)(g - 1), g);
     const unsigned eye_cells = 6u * (unsigned)G.g_eye * (unsigned)G.g_eye, sph_cells = 6u * (unsigned)G.g_sph * (unsigned)G.g_sph;
-    const unsigned base = of_eye ? (unsigned)f * eye_cells : 2u * eye_cells + (unsigned)s * sph_cells;
+    const unsigned base = of_eye ? G.eye_at + (unsigned)f * eye_cells : G.sph_at + (unsigned)s * sph_cells;
+    unsigned long long cell = 0;
+    if (has && member)
+        cell = G.path_lists[base + (unsigned)at];
+    fallback = active && (!has || !member || (unsigned)(cell >> 56) == TRT_LIST_NONE);
+    return cell;
+}
+
+// The same with the surface of every sphere cut into PATCHES that have a family each (GridView::patch_m > 0, trt_raygrid.h).
+// `fam`: the family code of the ray (0 eye, 1 mirror eye, 2 + i: it starts on
+// sphere i -- the patch of the sphere's surface follows from the origin --, 2 + n + (i << TRT_PATCH_SHIFT | k): reflected by the
+// ground, its parent started on patch k of sphere i; < 0 none).  `fam` becomes the family code of the ray's REFLECTION BY THE
+// GROUND, should it go on to hit the ground: the mirror family of this one's -- of the patch the ray started on -- or none (a ray
+// from the ground cannot hit the ground again).  `fallback` is set for an active lane whose ray fails the family's
+// membership test (its line must pass within r_chk of the apex, its origin not more than r_chk behind it, within the table's
+// range; a unit direction) or whose cell has no list: the caller then sweeps.
+TRT_DEV unsigned long long path_cell_patches(const LdsImage &L, const GridView &G, int n, int &fam, d3 o, d3 d, bool active, bool &fallback)
+{
+    const bool has = active && fam >= 0;
+    const int f = has ? fam : 0;
+    const bool of_eye = f < 2, mirrored = f >= 2 + n;
+    const int code = f - 2 - n; // mirrored: sphere and patch
+    const int i = mirrored ? code >> TRT_PATCH_SHIFT : (of_eye ? 0 : f - 2); // sphere of the family
+    // ONE record read per lane, from wherever the family's base point lives (all of it is in LDS: the choice is a 32-bit
+    // select of the address): the sphere's centre, its mirror image, or the eye / mirror eye, whose families are "patches" of
+    // a sphere of radius 0 -- base + 0 t is the base, 0 rho + slack the slack
+    const double *at_sphere = L.sph + 4 * i, *at_mirror = L.fam + 4 * i;
+    const double *src = of_eye ? L.eye + TRT_RAYFAMILY_DOUBLES * (f & 1) : (mirrored ? at_mirror : at_sphere);
+    const d3 base_at = load3(src);
+    // which patch of its sphere the ray starts on (FP32: the membership test below is what counts)
+    const int here = trt_cubemap_cell((float)(o.x - base_at.x), (float)(o.y - base_at.y), (float)(o.z - base_at.z), 0.5f * (float)G.patch_m,
+                                      (float)(G.patch_m - 1), G.patch_m);
+    const int k = mirrored ? code & ((1 << TRT_PATCH_SHIFT) - 1) : (of_eye ? 0 : here);
+    fam = f == 0 ? 1 : (!of_eye && !mirrored ? 2 + n + (((f - 2) << TRT_PATCH_SHIFT) | k) : -1);
+    const double r_abs = of_eye ? 0.0 : at_mirror[3];
+    const double *pr = L.patch + TRT_PATCH_RECORD * k + (mirrored ? 4 : 0);
+    const d3 apex = d3{TRT_PATCH_APEX(base_at.x, r_abs, pr[0]), TRT_PATCH_APEX(base_at.y, r_abs, pr[1]), TRT_PATCH_APEX(base_at.z, r_abs, pr[2])};
+    const double rho = pr[3];
+    // the eye's own radius and range come from LDS, the spheres' from the kernel's arguments.  Values first, selects after: a
+    // select between a POINTER into LDS and one to the (re-read) arguments is a flat load from a private copy
+    double rchk_eye = src[3], rg2_eye = src[5]; // only meaningful where src is a family of the eye
+    asm("" : "+v"(rchk_eye), "+v"(rg2_eye));
+    double r_chk = TRT_PATCH_RCHK(r_abs, rho, G.slack0), rg2 = G.rg2_sph;
+    r_chk = mirrored ? r_chk + TRT_FAMILY_SLACK : r_chk;
+    r_chk = of_eye ? rchk_eye : r_chk;
+    rg2 = of_eye ? rg2_eye : rg2;
+    // trt_rayfamily_member, operation for operation (all four conditions evaluated: no branches between them)
+    const d3 w = sub(o, apex);
+    const d3 c = d3{w.y * d.z - w.z * d.y, w.z * d.x - w.x * d.z, w.x * d.y - w.y * d.x};
+    const bool near_line = dot(c, c) <= r_chk * r_chk, ahead = dot(w, d) >= -r_chk, in_range = dot(w, w) <= rg2;
+    const bool unit_dir = __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
+    const bool member = near_line & ahead & in_range & unit_dir;
+    const int g = of_eye ? G.g_eye : G.g_sph;
+    const int at = trt_cubemap_cell((float)d.x, (float)d.y, (float)d.z, 0.5f * (float)g, (float)(g - 1), g);
+    const unsigned eye_cells = 6u * (unsigned)G.g_eye * (unsigned)G.g_eye, sph_cells = 6u * (unsigned)G.g_sph * (unsigned)G.g_sph;
+    const unsigned table = ((mirrored ? (unsigned)n : 0u) + (unsigned)i) * (unsigned)G.patch_count + (unsigned)k;
+    const unsigned base = of_eye ? G.eye_at + (unsigned)f * eye_cells : G.sph_at + table * sph_cells;
     unsigned long long cell = 0;
     if (has && member)
         cell = G.path_lists[base + (unsigned)at];
@@ -486,8 +550,9 @@ struct PathHit
 // P: closest hit of the path ray (o, d) of every lane with `alive`, candidates from the table of the ray's family `fam`
 // (trt_raygrid.h) unless some lane's ray is not a member of its family; then the surface record.  `fam` becomes the family of
 // the NEXT path ray: it starts on the sphere that was hit, or it is the mirror image in the ground of a ray of this one's
-// family (a ray from the ground cannot hit the ground again; if it does, it has no family).
-template <bool COUNT, bool REFRACT = false>
+// family -- of the patch of its sphere this ray started on -- (a ray from the ground cannot hit the ground again; if it
+// does, it has no family).
+template <bool COUNT, bool REFRACT = false, bool PATCHES = false>
 TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridView &grids, int n, d3 o, d3 d, int &fam, bool alive, d3 gp, d3 gn,
                            Tally &tally, int inside = -1)
 {
@@ -497,7 +562,10 @@ TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridVi
     if (grids.path_enabled)
     {
         bool fallback;
-        p_cell = path_cell(L, grids, n, fam, o, d, alive, fallback);
+        if constexpr (PATCHES)
+            p_cell = path_cell_patches(L, grids, n, fam, o, d, alive, fallback); // fam: now what a reflection by the ground belongs to
+        else
+            p_cell = path_cell(L, grids, n, fam, o, d, alive, fallback);
         p_list = !__any(fallback);
     }
     if (COUNT && !p_list)
@@ -512,7 +580,7 @@ TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridVi
     r.hit = alive && r.ph.i >= 0;
     r.sky = alive && r.ph.i < 0;
     if (r.hit)
-        fam = r.ph.i < n ? 2 + r.ph.i : (fam == 0 ? 1 : (fam >= 2 && fam < 2 + n ? fam + n : -1));
+        fam = r.ph.i < n ? 2 + r.ph.i : (PATCHES ? fam : (fam == 0 ? 1 : (fam >= 2 && fam < 2 + n ? fam + n : -1)));
     // one unit() for "back along the ray" (nudge, TRT.c:871-872) or the sky direction (TRT.c:702), one for the normal
     r.back = unit(r.hit ? sub(o, r.ph.p) : d);
     r.normal = d;
@@ -726,6 +794,7 @@ TRT_DEV GridView in_device_memory(GridView v)
     v.dir = in_device_memory(v.dir), v.point = in_device_memory(v.point);
     v.dir_lists = in_device_memory(v.dir_lists), v.point_lists = in_device_memory(v.point_lists);
     v.path_lists = in_device_memory(v.path_lists), v.pool = in_device_memory(v.pool), v.sphere_fam = in_device_memory(v.sphere_fam);
+    v.patch_rec = in_device_memory(v.patch_rec);
     return v;
 }
 #define TRT_FRESH_ARGS                                                                             \
@@ -747,10 +816,14 @@ constexpr int kCompactBlock = 256;
 constexpr int kCompactBlock = 1024;
 #endif // one workgroup per CU: 16 rings and one image share the CU's 160 KB of LDS
 
-template <bool COUNT, bool REFRACT = false, bool COMPACT = false>
+// PATCHES: the path rays' tables have a family per PATCH of a sphere's surface (GridView::patch_m > 0, trt_raygrid.h) instead of
+// one per sphere: another look-up (path_cell_patches), the same everything else.  Its own instantiation, so that scenes
+// without patches run the code -- and the register allocation -- they ran before there were any.
+template <bool COUNT, bool REFRACT = false, bool COMPACT = false, bool PATCHES = false>
 __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPACT && !COUNT && kCompactBlock == 1024) ? 4 : TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
 {
     static_assert(!(REFRACT && COMPACT), "the refraction extension runs on the plain rounds");
+    static_assert(!(PATCHES && COMPACT), "scenes with patches run the plain rounds");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const LdsImage L = stage_lds_image(lds, s, cull, f, grids);
     const int n = s.num_spheres, nd = s.num_dir, nl = s.num_dir + s.num_point;
@@ -870,7 +943,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         PathHit hit;
         {
             TRT_FRESH_ARGS;
-            hit = path_stage<COUNT, REFRACT>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside);
+            hit = path_stage<COUNT, REFRACT, PATCHES>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside);
         }
         if constexpr (COMPACT)
         {
@@ -1116,6 +1189,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
 // trt_probe_rays through the PRODUCTION stages: one lane per ray, the very path_stage / shadow_stage of the render kernel
 // (tables, fall-back sweep, exact tests, lighting).  families[i]: the family ray i is looked up in (trt_raygrid.h; < 0: none,
 // the wave sweeps); nullptr: none for every ray.  Outputs as trace_ray / apply_lighting produce them (TRT.c:793-963).
+template <bool PATCHES>
 __global__ __launch_bounds__(kPersistentBlock) void probe_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids, const double *rays,
                                                                         const int *families, long count, int *obj, double *point, double *normal,
                                                                         double *material, double *lit_out)
@@ -1130,7 +1204,7 @@ __global__ __launch_bounds__(kPersistentBlock) void probe_rounds_kernel(SceneVie
     const d3 o = load3(rays + 6 * at), d = load3(rays + 6 * at + 3);
     int fam = families ? families[at] : -1;
     Tally tally;
-    const PathHit hit = path_stage<false>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally);
+    const PathHit hit = path_stage<false, false, PATCHES>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally);
     const d3 surface = hit.hit ? add(hit.ph.p, scale(hit.back, 0.000001)) : o; // TRT.c:873-874 / :860
     const d3 lit = shadow_stage<false>(L, cull, grids, n, nd, nl, surface, hit.normal, hit.mat, hit.hit, gp, gn, tally);
     if (!alive)

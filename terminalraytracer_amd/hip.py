@@ -72,6 +72,9 @@ SYMBOLS = {
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
     "trt_set_path_grids": (_I, [_VP, _I, _I]),
     "trt_set_path_grids_min_spheres": (_I, [_VP, _I]),
+    "trt_set_path_patches": (_I, [_VP, _I]),
+    "trt_get_path_patches": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
+    "trt_path_family_code": (_I, [_VP, _I, _I, _VP]),
     "trt_set_compaction": (_I, [_VP, _I]),
     "trt_render_variant": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
     "trt_read_path_tables": (C.c_long, [_VP, C.POINTER(L.Camera), _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_long)]),
@@ -192,6 +195,31 @@ class Context:
     def set_path_grids(self, eye_cells, sphere_cells):
         """cells per cube-map face side of the path rays' family tables; 0, 0 = off (trt_set_path_grids)"""
         _check(lib().trt_set_path_grids(self._h, eye_cells, sphere_cells))
+
+    def set_path_patches(self, m):
+        """sub-families of the spheres: 6 m^2 patches per sphere; 0 = one family per sphere, -1 = by the number of spheres (trt_set_path_patches)"""
+        _check(lib().trt_set_path_patches(self._h, m))
+
+    def path_patches(self):
+        """(m, patches per sphere) of the current scene's tables (trt_get_path_patches)"""
+        m, p = _I(), _I()
+        _check(lib().trt_get_path_patches(self._h, C.byref(m), C.byref(p)))
+        return m.value, p.value
+
+    def family_codes(self, families, rays, num_spheres):
+        """The kernel's family codes (trt_path_family_code) for rays stored along chains: families[j] in the numbering 0 eye,
+        1 mirror eye, 2 + s starts on sphere s, 2 + N + s reflected by the ground with a parent that started on sphere s --
+        that parent is ray j - 1 of the chain, whose origin names the patch."""
+        families = np.asarray(families, dtype=np.int32)
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        out = families.copy()
+        n = num_spheres
+        for j in np.nonzero(families >= 2 + n)[0]:
+            s = int(families[j]) - 2 - n
+            assert j > 0 and families[j - 1] == 2 + s, "a mirror ray's parent must precede it"
+            parent = np.ascontiguousarray(rays[j - 1, :3])
+            out[j] = lib().trt_path_family_code(self._h, 3, s, parent.ctypes.data)
+        return out
 
     def set_path_grids_min_spheres(self, min_spheres):
         """scenes with fewer spheres keep the sweep for their path rays (trt_set_path_grids_min_spheres)"""

@@ -1,10 +1,10 @@
 /* raygrid_check.c -- host-side validation of the path-ray candidate tables (csrc/trt_raygrid.h).
  * Test helper only: compiled by tests/test_raygrid.py with gcc -O2 -ffp-contract=off -fopenmp.
  *
- * Builds the tables of all 2 + 2N families with the host reference builder, packs them into list cells exactly as the
- * library does, and walks path rays in trace order the way the kernel does: a ray that starts at the eye belongs to
- * family 0; otherwise the family follows from what the PREVIOUS path ray hit (sphere i -> 2 + i, ground -> the mirror
- * family of the parent's).  For every ray that passes the run-time membership test of its family, every sphere the
+ * Builds the tables of all 2 + 2NP families (P patches per sphere, trt_raygrid.h) with the host reference builder, packs
+ * them into list cells exactly as the library does, and walks path rays in trace order the way the kernel does: a ray that
+ * starts at the eye belongs to family 0; otherwise the family follows from what the PREVIOUS path ray hit (sphere i -> the
+ * patch of sphere i its origin lies on, ground -> the mirror family of the parent's).  For every ray that passes the run-time membership test of its family, every sphere the
  * EXACT reference test hits (TRT.c:638-672, FP64, reference operation order) must be in the list of the ray's cell.
  * `brute` additionally tests the ray against EVERY family whose membership test it passes (the tables must be
  * conservative for any member ray, wherever it came from). */
@@ -71,8 +71,9 @@ static int closest(const double *spheres, int n, const double *ground, const dou
 typedef struct
 {
     int n, g_eye, g_sph, families;
+    trt_patchset patches; /* the sub-families of every sphere (trt_raygrid.h): P = patches.count tables per sphere, and P mirrored */
     trt_rayfamily *fam;
-    unsigned long long *cells; /* list cells: 2 * 6 g_eye^2, then 2n * 6 g_sph^2 */
+    unsigned long long *cells; /* list cells: 2 * 6 g_eye^2, then 2 n P * 6 g_sph^2 */
     unsigned long long *pool;
     size_t pool_words, pool_cap;
 } tables;
@@ -83,24 +84,48 @@ static size_t family_base(const tables *T, int f)
     return f < 2 ? (size_t)f * ce : 2 * ce + (size_t)(f - 2) * cs;
 }
 
-/* the families of a scene in the library's order: eye, mirror eye, n spheres, n mirror spheres */
-void raygrid_families(const double *spheres, int n, const double *ground, const double *eye, trt_rayfamily *fam)
+/* the families of a scene in the library's order: eye, mirror eye, n P patches of the spheres, n P mirror images of them */
+void raygrid_families(const double *spheres, int n, const double *ground, const double *eye, int patch_m, trt_rayfamily *fam)
 {
+    trt_patchset P;
+    trt_patchset_init(&P, patch_m);
+    trt_family_consts consts;
     const int padded = trt_cull_padded(n, 8);
     float *table = (float *)malloc(sizeof(float) * 4 * (size_t)(padded ? padded : 1));
     trt_cull_scene cs;
     trt_cull_build(spheres, n, 8, table, &cs);
     free(table);
     trt_eye_families(eye, ground, &cs, fam);
-    trt_sphere_families(spheres, n, ground, &cs, fam + 2);
+    trt_sphere_families(spheres, n, ground, &cs, &P, fam + 2, NULL, &consts);
 }
 
-static tables *build(const double *spheres, int n, const double *ground, const double *eye, int g_eye, int g_sph, ray_stats *st)
+/* table of the family a path ray with the kernel's family code `code` is looked up in (trt_raygrid.h: 0 eye, 1 mirror eye,
+ * 2 + i sphere i -- the patch follows from the origin --, 2 + n + (i << TRT_PATCH_SHIFT | k) mirror image of patch k of sphere i) */
+static int table_of(const tables *T, const double *spheres, int code, const double *o, int *patch_out)
+{
+    const int n = T->n, P = T->patches.count;
+    *patch_out = 0;
+    if (code < 2)
+        return code;
+    if (code < 2 + n)
+    {
+        const int i = code - 2;
+        const int k = trt_patch_of(T->patches.m, o[0] - spheres[9 * i], o[1] - spheres[9 * i + 1], o[2] - spheres[9 * i + 2]);
+        *patch_out = k;
+        return 2 + i * P + k;
+    }
+    const int s = code - 2 - n, i = s >> TRT_PATCH_SHIFT, k = s & ((1 << TRT_PATCH_SHIFT) - 1);
+    *patch_out = k;
+    return 2 + (n + i) * P + k;
+}
+
+static tables *build(const double *spheres, int n, const double *ground, const double *eye, int g_eye, int g_sph, int patch_m, ray_stats *st)
 {
     tables *T = (tables *)calloc(1, sizeof *T);
-    T->n = n, T->g_eye = g_eye, T->g_sph = g_sph, T->families = 2 + 2 * n;
+    trt_patchset_init(&T->patches, patch_m);
+    T->n = n, T->g_eye = g_eye, T->g_sph = g_sph, T->families = 2 + 2 * n * T->patches.count;
     T->fam = (trt_rayfamily *)malloc(sizeof(trt_rayfamily) * (size_t)T->families);
-    raygrid_families(spheres, n, ground, eye, T->fam);
+    raygrid_families(spheres, n, ground, eye, patch_m, T->fam);
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
     const size_t total = family_base(T, T->families);
     T->cells = (unsigned long long *)malloc(sizeof(unsigned long long) * total);
@@ -199,10 +224,10 @@ static void note(ray_stats *st, const double *ray, int sphere, int family)
 
 /* rays: n_rays x 6 doubles in trace order, kinds[r] == 0 marks path rays (other rays are skipped) */
 void raygrid_check(const double *spheres, int n, const double *ground, const double *eye, const double *rays, const unsigned char *kinds,
-                   size_t n_rays, int g_eye, int g_sph, int brute, ray_stats *st)
+                   size_t n_rays, int g_eye, int g_sph, int patch_m, int brute, ray_stats *st)
 {
     memset(st, 0, sizeof *st);
-    tables *T = build(spheres, n, ground, eye, g_eye, g_sph, st);
+    tables *T = build(spheres, n, ground, eye, g_eye, g_sph, patch_m, st);
     int src = -1;
     unsigned group_max = 0;
     size_t seen = 0;
@@ -216,7 +241,9 @@ void raygrid_check(const double *spheres, int n, const double *ground, const dou
             src = 0; /* a new sample */
         st->rays++;
         unsigned long long cell = 0;
-        const int cand = src >= 0 ? lookup(T, src, o, d, &cell) : -1;
+        int patch = 0;
+        const int table = src >= 0 ? table_of(T, spheres, src, o, &patch) : -1;
+        const int cand = src >= 0 ? lookup(T, table, o, d, &cell) : -1;
         if (cand < 0)
         {
             st->non_members++;
@@ -270,20 +297,20 @@ void raygrid_check(const double *spheres, int n, const double *ground, const dou
         else if (what < n)
             src = 2 + what;
         else
-            src = src == 0 ? 1 : (src >= 2 && src < 2 + n ? src + n : -1);
+            src = src == 0 ? 1 : (src >= 2 && src < 2 + n ? 2 + n + (((src - 2) << TRT_PATCH_SHIFT) | patch) : -1);
     }
     destroy(T);
 }
 
 /* the host reference tables as list cells + pool, for the GPU test that compares the device-built tables: returns the pool
- * words used; cells must hold 2*6*g_eye^2 + 2n*6*g_sph^2 words.  Cells are compared through their entries (the pool
+ * words used; cells must hold 2*6*g_eye^2 + 2nP*6*g_sph^2 words (P patches per sphere).  Cells are compared through their entries (the pool
  * offsets depend on the order in which cells reserve their words). */
-long raygrid_host_cells(const double *spheres, int n, const double *ground, const double *eye, int g_eye, int g_sph, unsigned long long *cells,
-                        unsigned long long *pool, long pool_cap)
+long raygrid_host_cells(const double *spheres, int n, const double *ground, const double *eye, int g_eye, int g_sph, int patch_m,
+                        unsigned long long *cells, unsigned long long *pool, long pool_cap)
 {
     ray_stats st;
     memset(&st, 0, sizeof st);
-    tables *T = build(spheres, n, ground, eye, g_eye, g_sph, &st);
+    tables *T = build(spheres, n, ground, eye, g_eye, g_sph, patch_m, &st);
     const size_t total = family_base(T, T->families);
     memcpy(cells, T->cells, total * sizeof(unsigned long long));
     const long used = (long)T->pool_words;

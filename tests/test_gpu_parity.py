@@ -82,14 +82,17 @@ def _same_probe(got, want, hit_only_lit=True):
     assert np.array_equal(bits(lit[hit]), bits(want["lit"][hit]))
 
 
-@pytest.mark.parametrize("grids", [(64, 32), (5, 3), (0, 0)], ids=["default_tables", "coarse_tables", "sweep_only"])
+@pytest.mark.parametrize("grids", [(64, 32, 0), (64, 16, 2), (40, 8, 3), (5, 3, 1), (0, 0, 0)],
+                         ids=["default_tables", "24_patches", "54_patches", "coarse_tables_6_patches", "sweep_only"])
 def test_production_stages_match_reference_single_ray_vectors(ctx, grids):
     """trace_ray, ray_intersects_sphere/plane, get_skybox_color and apply_lighting (TRT.c:638-963), each through the code that
     SHIPS: the probe runs the render kernel's own path_stage / shadow_stage.  (a) the 600 arbitrary rays of rays.npz (no
     family: every wave sweeps; non-unit directions among them); (b) chains of path rays as project_scene produces them, every
-    ray looked up in the table of its family -- eye, mirror eye, spheres, mirror spheres -- 64 spheres with mirrors and 256."""
+    ray looked up in the table of its family -- eye, mirror eye, spheres (one family per sphere, or 6 / 24 / 54 patches per sphere
+    with a family each), their mirror images -- 64 spheres with mirrors and 256."""
     try:
-        ctx.set_path_grids(*grids)
+        ctx.set_path_patches(grids[2])
+        ctx.set_path_grids(*grids[:2])
         d = np.load(T.GOLDEN + "/rays.npz")
         scene = S.SceneData.from_arrays(d, T.sky("uv_checker"), prefix="scene/")
         ctx.set_scene(scene)
@@ -99,12 +102,15 @@ def test_production_stages_match_reference_single_ray_vectors(ctx, grids):
             scene = S.SceneData.from_arrays(fam, T.sky("uv_checker"), prefix=tag + "/scene/")
             want = {k: fam[f"{tag}/{k}"] for k in ("obj", "point", "normal", "material", "lit")}
             ctx.set_scene(scene)
-            _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], fam[tag + "/families"]), want)
+            codes = ctx.family_codes(fam[tag + "/families"], fam[tag + "/rays"], len(scene.spheres)) if grids[0] else fam[tag + "/families"]
+            assert ctx.path_patches() == ((grids[2], max(1, 6 * grids[2] ** 2)) if grids[0] else (0, 0))
+            _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], codes), want)
             # a WRONG family must not matter either: the membership test sends such rays to the sweep
-            wrong = np.roll(fam[tag + "/families"], 7)
+            wrong = np.roll(codes, 7)
             _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], wrong), want)
             _same_probe(ctx.probe_rays(fam[tag + "/rays"]), want)  # and the reference-order kernel's probe
     finally:
+        ctx.set_path_patches(-1)
         ctx.set_path_grids(64, 32)
 
 
@@ -577,10 +583,12 @@ def _decode_cells(cells, pool):
     return out
 
 
-@pytest.mark.parametrize("cells", [(0, 0), (2, 2), (9, 5), (64, 32), (128, 48)], ids=["off", "coarsest", "odd", "default", "fine"])
+@pytest.mark.parametrize("cells", [(0, 0, 0), (2, 2, 0), (9, 5, 0), (64, 32, 0), (128, 48, 0), (64, 32, -1), (64, 16, 2), (7, 3, 1), (32, 8, 4), (48, 12, 3)],
+                         ids=["off", "coarsest", "odd", "one_family_per_sphere", "fine", "default", "24_patches", "coarse_6_patches", "96_patches", "54_patches"])
 def test_path_ray_tables_never_change_a_frame(ctx, cells):
     """A path ray's candidate spheres come from the direction table of its family (csrc/trt_raygrid.h): the eye, its mirror
-    image in the ground, the sphere it starts on, that sphere's mirror image.  Whatever the tables' resolution -- or with them
+    image in the ground, the sphere it starts on (the whole sphere or one of 6 m^2 patches of it), that family's mirror image.
+    Whatever the tables' resolution and the number of patches -- or with the tables
     off, every path ray sweeping -- frames must equal the oracle bit for bit and the trace counts the reference's: 64 and 256
     spheres, mirror-heavy materials (long chains of families), a tilted ground with a non-unit normal, a perfect-mirror
     floor, the eye inside a sphere, touching / nested / duplicated / huge / tiny spheres, a moving eye (tables rebuilt)."""
@@ -592,7 +600,8 @@ def test_path_ray_tables_never_change_a_frame(ctx, cells):
     base = S.synth_scene(64, T.sky("synth"), T.bench_camera(48, 27))
     cases += [(base.with_camera(T.bench_camera(48, 27, t)), 48, 27, 6, 2) for t in (0.0, 0.5, 33.3)]  # same spheres, the eye moves
     try:
-        ctx.set_path_grids(*cells)
+        ctx.set_path_patches(cells[2])
+        ctx.set_path_grids(*cells[:2])
         ctx.enable_counters(True)
         for scene, w, h, b, spp in cases:
             with np.errstate(all="ignore"):
@@ -600,8 +609,13 @@ def test_path_ray_tables_never_change_a_frame(ctx, cells):
             got = render(ctx, scene, w, h, b, spp)
             assert np.array_equal(bits(got), bits(want)), (cells, len(scene.spheres))
             assert ctx.read_counters() == (st.path_rays, st.shadow_rays)
+            if cells[2] > 0 and cells[0] >= 32 and len(scene.spheres) >= 64 and w >= 64:
+                # the patches must SERVE the rays, not send them to the sweep: a wrong patch would still be bit-exact
+                diag = ctx.read_diagnostics()
+                assert diag["swept_traces"] < 0.05 * 3 * diag["wave_loop_trips"], (cells, diag)
     finally:
         ctx.enable_counters(False)
+        ctx.set_path_patches(-1)
         ctx.set_path_grids(64, 32)
 
 
@@ -742,18 +756,21 @@ def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
               S.SceneData(base.spheres, g, base.dir_lights, base.point_lights, base.camera, base.sky), R._odd_scenes()[4][1]]
     try:
         for scene in scenes:
-            for ge, gs in ((64, 32), (11, 3)):
+            for ge, gs, m in ((64, 32, 0), (11, 3, 0), (64, 8, 2), (16, 6, 1)):
+                ctx.set_path_patches(m)
                 ctx.set_path_grids(ge, gs)
                 ctx.set_scene(scene)
                 info, cells, pool = ctx.read_path_tables(scene.camera)
                 n = len(scene.spheres)
-                assert info["enabled"] == 1 and info["cells"] == 2 * 6 * ge * ge + 2 * n * 6 * gs * gs == len(cells)
+                P = 6 * m * m if m else 1
+                assert ctx.path_patches() == (m, P)
+                assert info["enabled"] == 1 and info["cells"] == 2 * 6 * ge * ge + 2 * n * P * 6 * gs * gs == len(cells)
                 sph = np.ascontiguousarray(scene.spheres, dtype=np.float64)
                 ground = np.ascontiguousarray(scene.ground, dtype=np.float64)
                 eye = np.ascontiguousarray(scene.camera[9:12], dtype=np.float64)
                 want_cells = np.zeros(len(cells), dtype=np.uint64)
                 want_pool = np.zeros(len(cells) + 16, dtype=np.uint64)
-                used = lib.raygrid_host_cells(sph.ctypes.data, n, ground.ctypes.data, eye.ctypes.data, ge, gs, want_cells.ctypes.data,
+                used = lib.raygrid_host_cells(sph.ctypes.data, n, ground.ctypes.data, eye.ctypes.data, ge, gs, m, want_cells.ctypes.data,
                                               want_pool.ctypes.data, len(want_pool))
                 assert 0 <= used <= len(want_pool)
                 got, want = _decode_cells(cells, pool), _decode_cells(want_cells, want_pool)
@@ -764,6 +781,7 @@ def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
                 if ge == 64:  # the library's resolutions: every cell has its list
                     assert None not in got and None not in want
     finally:
+        ctx.set_path_patches(-1)
         ctx.set_path_grids(64, 32)
 
 

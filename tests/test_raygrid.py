@@ -35,9 +35,9 @@ def build_checker():
         subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-shared", "-I" + inc, "-o", so, src, "-lm"])
     lib = C.CDLL(so)
     lib.raygrid_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
-                                  C.POINTER(Stats)]
+                                  C.c_int, C.POINTER(Stats)]
     lib.raygrid_check.restype = None
-    lib.raygrid_host_cells.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
+    lib.raygrid_host_cells.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_long]
     lib.raygrid_host_cells.restype = C.c_long
     return lib
 
@@ -47,7 +47,7 @@ def checker():
     return build_checker()
 
 
-def run(checker, scene, rays, kinds, g_eye, g_sph, brute=False):
+def run(checker, scene, rays, kinds, g_eye, g_sph, brute=False, patch_m=0):
     sph = np.ascontiguousarray(scene.spheres, dtype=np.float64)
     ground = np.ascontiguousarray(scene.ground, dtype=np.float64)
     eye = np.ascontiguousarray(scene.camera[9:12], dtype=np.float64)
@@ -55,7 +55,7 @@ def run(checker, scene, rays, kinds, g_eye, g_sph, brute=False):
     kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
     st = Stats()
     checker.raygrid_check(sph.ctypes.data, sph.shape[0], ground.ctypes.data, eye.ctypes.data, rays.ctypes.data, kinds.ctypes.data,
-                          rays.shape[0], g_eye, g_sph, int(brute), C.byref(st))
+                          rays.shape[0], g_eye, g_sph, patch_m, int(brute), C.byref(st))
     return st
 
 
@@ -78,22 +78,30 @@ FRAMES = [("north-star scene, 64 spheres", lambda: S.synth_scene(64, T.sky("synt
 def test_path_tables_hold_every_exact_hit_on_real_frames(checker, name, make, w, h, b):
     scene = make()
     rays, kinds = traced_rays(scene, w, h, b, 10)
-    # the library's default resolution (64 / 32; 64 / 16 for the 256-sphere scene, whose host build would take a minute) and a very coarse one
-    for g_eye, g_sph in ((64, 32 if len(scene.spheres) <= 64 else 16), (7, 3)):
-        st = run(checker, scene, rays, kinds, g_eye, g_sph)
-        print(f"\n{name} g {g_eye}/{g_sph}: {describe(st)}")
+    # the library's default resolution (64 / 32; 64 / 16 for the 256-sphere scene, whose host build would take a minute), a very
+    # coarse one, and the spheres' surfaces cut into 24 patches with a family each (coarser cells: the host build is slow) and into 6
+    dense = len(scene.spheres) > 64
+    whole = None
+    for g_eye, g_sph, m in ((64, 16 if dense else 32, 0), (7, 3, 0), (64, 8 if dense else 16, 2), (9, 4, 1)):
+        st = run(checker, scene, rays, kinds, g_eye, g_sph, patch_m=m)
+        print(f"\n{name} g {g_eye}/{g_sph} patches m {m}: {describe(st)}")
         assert st.rays == int((kinds == 0).sum()) and st.violations == 0, list(st.first_violation)
         if g_eye == 64:  # the library's resolutions: no list is lost to the pool's capacity, nearly every path ray is served
             assert st.none_cells == 0 and st.members > 0.995 * st.rays
+            if m == 0:
+                whole = st
+            else:  # the patches serve the rays the whole-sphere families served, with fewer candidates although their cells are coarser
+                assert st.members >= whole.members - 8 and st.candidates < whole.candidates
 
 
 def test_any_family_a_ray_is_a_member_of_is_conservative_for_it(checker):
     """the structural assignment of families is a convenience: the membership test alone must make a table safe"""
     scene = S.synth_scene(64, T.sky("synth"), T.bench_camera(64, 36, 2.5))
     rays, kinds = traced_rays(scene, 64, 36, 8, 10)
-    st = run(checker, scene, rays, kinds, 32, 8, brute=True)
-    print("\n" + describe(st))
-    assert st.violations == 0 and st.brute_violations == 0 and st.brute_pairs >= st.members
+    for m in (0, 1):
+        st = run(checker, scene, rays, kinds, 32, 8, brute=True, patch_m=m)
+        print("\n" + describe(st))
+        assert st.violations == 0 and st.brute_violations == 0 and st.brute_pairs >= st.members
 
 
 def _odd_scenes():
@@ -131,6 +139,7 @@ def _odd_scenes():
 def test_path_tables_on_adversarial_scenes(checker, name, scene):
     with np.errstate(all="ignore"):
         rays, kinds = traced_rays(scene, 64, 36, 8, 10)
-    st = run(checker, scene, rays, kinds, 32, 8, brute=(name != "base"))
-    print(f"\n{name}: {describe(st)}")
-    assert st.violations == 0 and st.brute_violations == 0, list(st.first_violation)
+    for m, brute in ((0, name != "base"), (2, False), (1, name in ("tilted ground", "odd spheres"))):
+        st = run(checker, scene, rays, kinds, 32, 8, brute=brute, patch_m=m)
+        print(f"\n{name}, patches m {m}: {describe(st)}")
+        assert st.violations == 0 and st.brute_violations == 0, list(st.first_violation)
