@@ -9,6 +9,9 @@ BUILD := build
 # -fno-slp-vectorize: packed FP32 (v_pk_fma_f32) buys nothing on gfx950 and costs registers.
 # extra -D switches for kernel-tuning A/B builds, e.g. make lib LIB=build/w4.so TUNE=-DTRT_PERSISTENT_WAVES=4
 TUNE ?=
+empty :=
+space := $(empty) $(empty)
+TAG := $(subst $(space),,$(subst =,_,$(subst -D,_,$(TUNE))))
 HIPFLAGS := $(TUNE) --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -std=c++17 \
             -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 HOSTFLAGS := -O2 -ffp-contract=off -fno-fast-math -fPIC -std=c11 -Iinclude -Wall -Wextra
@@ -24,19 +27,19 @@ $(BUILD)/host_%.o: $(CSRC)/host/%.c include/trt.h include/trt_host.h
 	@mkdir -p $(BUILD)
 	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
-$(BUILD)/trt_capi$(subst =,_,$(subst -D,_,$(TUNE))).o: $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h
+$(BUILD)/trt_capi$(TAG).o: $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o $@ $(CSRC)/trt_capi.hip 2> $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt \
-		|| (cat $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt; false)
-	@grep -E "error|warning:" $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt || true
-	@awk '/Function Name: .*render_rounds_kernelILb0/ {f=1} f && /VGPRs:/ {split($$0,a,"VGPRs: "); v=a[2]+0; print "render_rounds_kernel<false>: " v " VGPRs" (v>128 ? "  ** WARNING: more than 128 -> 3 waves/SIMD **" : " (4 waves/SIMD)"); exit}' $(BUILD)/resource_usage$(subst =,_,$(subst -D,_,$(TUNE))).txt
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o $@ $(CSRC)/trt_capi.hip 2> $(BUILD)/resource_usage$(TAG).txt \
+		|| (cat $(BUILD)/resource_usage$(TAG).txt; false)
+	@grep -E "error|warning:" $(BUILD)/resource_usage$(TAG).txt || true
+	@awk '/Function Name: .*render_rounds_kernelILb0/ {f=1} f && /VGPRs:/ {split($$0,a,"VGPRs: "); v=a[2]+0; print "render_rounds_kernel<false>: " v " VGPRs" (v>128 ? "  ** WARNING: more than 128 -> 3 waves/SIMD **" : " (4 waves/SIMD)"); exit}' $(BUILD)/resource_usage$(TAG).txt
 
 $(BUILD)/trt_dist.o: $(CSRC)/trt_dist.hip include/trt.h include/trt_hip.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/trt_dist.hip
 
 # RCCL is bound at run time by trt_dist.hip (dlopen): the library does not link against it
-$(LIB): $(BUILD)/trt_capi$(subst =,_,$(subst -D,_,$(TUNE))).o $(BUILD)/trt_dist.o $(HOST_OBJ)
+$(LIB): $(BUILD)/trt_capi$(TAG).o $(BUILD)/trt_dist.o $(HOST_OBJ)
 	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $< $(BUILD)/trt_dist.o $(HOST_OBJ) -ldl
 
 demo: examples/trt_demo examples/trt_dist_demo
