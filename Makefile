@@ -18,8 +18,8 @@ HOSTFLAGS := -O2 -ffp-contract=off -fno-fast-math -fPIC -std=c11 -Iinclude -Wall
 HOST_SRC := $(wildcard $(CSRC)/host/*.c)
 HOST_OBJ := $(patsubst $(CSRC)/host/%.c,$(BUILD)/host_%.o,$(HOST_SRC))
 
-.PHONY: all lib demo oracle clean resource-usage
-all: lib demo oracle
+.PHONY: all lib demo oracle stub clean resource-usage
+all: lib demo oracle stub
 
 lib: $(LIB)
 
@@ -48,6 +48,13 @@ examples/%: examples/%.c $(LIB) include/trt_hip.h include/trt_host.h
 
 oracle:
 	$(MAKE) -C oracle all
+
+# TEST INFRASTRUCTURE: a stand-in for the eight RCCL entry points trt_dist.hip binds, so that several ranks can share the one GPU of a
+# test box (selected by TRT_RCCL_LIB, tests only)
+stub: tests/_build/librccl_stub.so
+tests/_build/librccl_stub.so: tests/rccl_stub.cpp
+	@mkdir -p tests/_build
+	g++ -O2 -fPIC -shared -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o $@ $< -L/opt/rocm/lib -lamdhip64 -lrt -lpthread
 
 # compiler's view of registers / LDS / occupancy per kernel
 resource-usage:

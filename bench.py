@@ -200,7 +200,11 @@ def main():
         args.no_verify = True  # the reference's hashes are for the 256^2 cubemap
     cameras = animation_cameras(width, height, args.animation) if args.animation > 0 else [scene.camera]
     camera_of = lambda step: cameras[step % len(cameras)]  # noqa: E731
-    rehearsal = world > 1 and args.backend != "nccl"
+    # --backend gloo: several ranks may share one GPU, which RCCL cannot do: the PyTorch-level rehearsal path -- unless
+    # TRT_RCCL_LIB names a stand-in for RCCL (tests/rccl_stub.cpp), with which the product path itself runs on one GPU
+    stand_in = os.environ.get("TRT_RCCL_LIB")
+    rehearsal = world > 1 and args.backend != "nccl" and not stand_in
+    carrier = f"cuda:{local}" if args.backend == "nccl" else "cpu"  # where torch.distributed's own tensors live
     fallback_reason = None
 
     def torch_level_renderer():  # PyTorch-level sharding: trt_render_device per rank, torch.distributed gather
@@ -213,7 +217,7 @@ def main():
     else:          # the product path: trt_dist_* behind the C-ABI
         uid = None
         if world > 1:
-            box = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local}")
+            box = torch.zeros(128, dtype=torch.uint8, device=carrier)
             if rank == 0:
                 box.copy_(torch.frombuffer(bytearray(hip.dist_unique_id()), dtype=torch.uint8))
             dist.broadcast(box, 0)
@@ -242,8 +246,13 @@ def main():
         worker.start()
         worker.join(timeout=180.0 if world > 1 else None)
         if worker.is_alive():
-            problem.append("no frame through trt_dist_* within 180 s")
-        ok = torch.tensor([0 if problem else 1], dtype=torch.int32, device=f"cuda:{local}")
+            # The thread is stuck inside the library (ncclCommInitRank or a GPU wait) and keeps its communicator and its streams on
+            # this GPU: nothing timed beside it would mean anything, and interpreter exit could block in its teardown.  Say so and
+            # leave -- the peers' next collective fails and they leave as well.  (An EXCEPTION, below, is a clean failure: then
+            # every rank falls back.)
+            print(f"bench: rank {rank}: no frame through trt_dist_* within 180 s; giving up", file=sys.stderr, flush=True)
+            os._exit(4)
+        ok = torch.tensor([0 if problem else 1], dtype=torch.int32, device=carrier)
         if world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
@@ -255,7 +264,7 @@ def main():
         else:
             fallback_reason = problem[0] if problem else "another rank failed"
             print(f"bench: rank {rank}: C-ABI multi-GPU path unavailable ({fallback_reason}); falling back to the PyTorch-level gather", file=sys.stderr)
-            if "dist" in made and not worker.is_alive():
+            if "dist" in made:
                 made["dist"].close()
             r, contexts, rowset, render, fetch = torch_level_renderer()
     for c in contexts:
@@ -275,7 +284,7 @@ def main():
         diag = diag or ctx0.read_diagnostics()
     ctx0.enable_counters(False)
     torch.cuda.synchronize()
-    counts = torch.tensor([path_per_cam, shadow_per_cam], dtype=torch.float64, device=f"cuda:{local}")
+    counts = torch.tensor([path_per_cam, shadow_per_cam], dtype=torch.float64, device=carrier)
     if world > 1:
         dist.all_reduce(counts)
     path_cam, shadow_cam = counts[0].cpu().numpy(), counts[1].cpu().numpy()
@@ -283,6 +292,10 @@ def main():
     shadow_timed = float(sum(shadow_cam[i % len(cameras)] for i in range(args.steps)))
 
     def barrier():
+        # the library's own work first: its communicator still has grouped send/recv queued on its stream, and torch's barrier is
+        # a collective on ANOTHER communicator of the same GPU -- two communicators with work in flight, issued in an order that
+        # differs from rank to rank, is the documented NCCL/RCCL deadlock
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -317,7 +330,7 @@ def main():
     for i in range(args.steps):
         last = render(camera_of(i))
     barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local}")
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=carrier)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     seconds = float(elapsed.item())
@@ -362,7 +375,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["text"] if args.sky_dim == SKY_DIM else wl["text"].replace("256^2", f"{args.sky_dim}^2"), "sharding": f"{world} x interleaved {args.tile_rows}-row tiles, 1 gather/frame",
                        "multi_gpu_path": "PyTorch-level rehearsal (gloo)" if rehearsal else
-                                         ("C-ABI trt_dist_* (RCCL send/recv gather inside the library)" if fallback_reason is None else
+                                         ("C-ABI trt_dist_* (send/recv gather inside the library) over a STAND-IN for RCCL: " + stand_in if stand_in and world > 1 else
+                                          "C-ABI trt_dist_* (RCCL send/recv gather inside the library)" if fallback_reason is None else
                                           "FALLBACK: PyTorch-level gather (torch.distributed " + args.backend + "); trt_dist_* failed: " + fallback_reason),
                        "kernel": {0: "persistent waves, synchronous rounds" + (", shading decoupled from the owning lane" if variant["decoupled"] else ""),
                                   1: "reference-order"}[args.kernel],

@@ -47,6 +47,9 @@ void project_scene(Scene *scene, Screen *screen);
 
 /* project_scene with the two macros as run-time values (TRT.c:54, TRT.c:58).  Host in, host out. */
 int trt_render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_per_pixel);
+/* The same entry under the name BASELINE.json's north_star gives it ("render_frame() entry"; the reference itself has no such
+ * symbol: its frame producer is project_scene, TRT.c:966). */
+int render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_per_pixel);
 
 /* The same frame as the bytes the emitter makes of it: rgb[(row*width + col)*3 + channel] = (int)(colour*255), the
  * conversion of buffered_draw_screen (TRT.c:1157-1163) done on the device, so that 3 bytes per pixel cross PCIe instead of 24.
@@ -268,7 +271,8 @@ const char *trt_version(void);
  * pixel is independent.  Here one rank = one process (or thread) = one GPU; the ranks render interleaved tiles of
  * `tile_rows` rows each (tile t -> rank t mod world) and ONE gather per frame brings the rows to rank 0 over RCCL
  * (ncclSend / ncclRecv inside one group on the library's own stream; over xGMI every peer has its own link to the root).
- * Frames are pipelined over `frames_in_flight` renderer contexts.  RCCL is loaded at run time and only for world > 1.
+ * Frames are pipelined over `frames_in_flight` renderer contexts.  RCCL is loaded at run time (librccl.so.1; the environment
+ * variable TRT_RCCL_LIB names another library with the same entry points -- the tests' stand-in) and only for world > 1.
  * The host program carries the 128-byte id from rank 0 to the other ranks however it likes (MPI, a file, a socket,
  * torch.distributed): it is what ncclGetUniqueId produced. */
 typedef struct trt_dist trt_dist;
@@ -289,7 +293,17 @@ int trt_dist_set_scene(trt_dist *d, const Scene *scene);
  * Screen layout of TRT.c:188-193 (NULL on the other ranks); it is complete after trt_dist_synchronize and is reused
  * `frames_in_flight` calls later. */
 int trt_dist_render(trt_dist *d, const Camera *camera, int bounce_limit, int rays_per_pixel, void **d_frame);
+/* If a collective fails on a rank (a HIP or RCCL error after the call has started to enqueue work), that rank is out of step
+ * with its peers: the trt_dist is poisoned, every later render / synchronize call on it fails with TRT_ERR_NOT_INITIALISED,
+ * and the host should destroy it on every rank. */
 int trt_dist_synchronize(trt_dist *d);
+/* The same frame as the 3 bytes per pixel the emitter makes of it ((int)(c*255), TRT.c:1157-1163): every rank
+ * quantises its rows on the device and the gather moves bytes -- 8 times less over xGMI than doubles -- into an assembled
+ * height x width x 3 byte frame on rank 0, bit-exact for buffered_draw_screen.  trt_dist_enable_rgb8 allocates the byte
+ * buffers (once, on every rank, before the first trt_dist_render_rgb8); the two kinds of frame may be mixed. */
+int trt_dist_enable_rgb8(trt_dist *d);
+int trt_dist_render_rgb8(trt_dist *d, const Camera *camera, int bounce_limit, int rays_per_pixel, void **d_frame_rgb8);
+int trt_dist_fetch_rgb8(trt_dist *d, const void *d_frame_rgb8, unsigned char *rgb);
 /* synchronise, then copy an assembled frame into screen->pixels-like host memory (width*height Vectors) */
 int trt_dist_fetch(trt_dist *d, const void *d_frame, Vector *pixels);
 /* The root's assembly map, pure host arithmetic (no GPU): source_row[frame row] = row of the rank-major gather buffer in

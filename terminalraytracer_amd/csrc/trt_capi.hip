@@ -1821,6 +1821,12 @@ extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_l
     return trt_render_host(ctx, &scene->camera, &whole, bounce_limit, rays_per_pixel, screen->pixels);
 }
 
+// north_star's name for the entry: the frame producer with the two macros of TRT.c:54, :58 as run-time values
+extern "C" int render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_per_pixel)
+{
+    return trt_render_frame(scene, screen, bounce_limit, rays_per_pixel);
+}
+
 extern "C" int trt_render_host_rgb8(trt_context *ctx, const Camera *camera, const trt_rowset *rows, int bounce_limit, int rays_per_pixel,
                                     unsigned char *rgb)
 {

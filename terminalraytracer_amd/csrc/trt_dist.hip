@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 namespace
@@ -63,43 +64,50 @@ struct Rccl
     char why[256] = "";
 };
 
+// Bound once, by whichever thread comes first (one rank may be one THREAD per GPU: trt_hip.h); the struct is published only
+// after every symbol is bound.  TRT_RCCL_LIB names another library with the same eight entry points (the tests' stand-in
+// that lets several ranks share one GPU, tests/rccl_stub.cpp); the product never sets it.
 Rccl *rccl()
 {
     static Rccl lib;
-    static bool tried = false;
-    if (tried)
-        return lib.handle ? &lib : nullptr;
-    tried = true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *name : names)
-        if ((lib.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
-            break;
-    if (!lib.handle)
-    {
-        snprintf(lib.why, sizeof lib.why, "%s", dlerror());
-        return nullptr;
-    }
-    bool ok = true;
-    auto bind = [&](const char *symbol) {
-        void *p = dlsym(lib.handle, symbol);
-        ok = ok && p;
-        return p;
-    };
-    lib.GetUniqueId = (decltype(lib.GetUniqueId))bind("ncclGetUniqueId");
-    lib.CommInitRank = (decltype(lib.CommInitRank))bind("ncclCommInitRank");
-    lib.CommDestroy = (decltype(lib.CommDestroy))bind("ncclCommDestroy");
-    lib.GroupStart = (decltype(lib.GroupStart))bind("ncclGroupStart");
-    lib.GroupEnd = (decltype(lib.GroupEnd))bind("ncclGroupEnd");
-    lib.Send = (decltype(lib.Send))bind("ncclSend");
-    lib.Recv = (decltype(lib.Recv))bind("ncclRecv");
-    lib.GetErrorString = (decltype(lib.GetErrorString))bind("ncclGetErrorString");
-    if (!ok)
-    {
-        snprintf(lib.why, sizeof lib.why, "librccl lacks an entry point");
-        lib.handle = nullptr;
-        return nullptr;
-    }
-    return &lib;
+    static Rccl *published = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *override_name = getenv("TRT_RCCL_LIB");
+        const char *names[] = {override_name && *override_name ? override_name : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const int count = override_name && *override_name ? 1 : 3; // an override that cannot be loaded is an error, not a reason to look elsewhere
+        void *handle = nullptr;
+        for (int i = 0; i < count && !handle; i++)
+            handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!handle)
+        {
+            const char *why = dlerror();
+            snprintf(lib.why, sizeof lib.why, "%s", why ? why : "dlopen failed");
+            return;
+        }
+        bool ok = true;
+        auto bind = [&](const char *symbol) {
+            void *p = dlsym(handle, symbol);
+            ok = ok && p;
+            return p;
+        };
+        lib.GetUniqueId = (decltype(lib.GetUniqueId))bind("ncclGetUniqueId");
+        lib.CommInitRank = (decltype(lib.CommInitRank))bind("ncclCommInitRank");
+        lib.CommDestroy = (decltype(lib.CommDestroy))bind("ncclCommDestroy");
+        lib.GroupStart = (decltype(lib.GroupStart))bind("ncclGroupStart");
+        lib.GroupEnd = (decltype(lib.GroupEnd))bind("ncclGroupEnd");
+        lib.Send = (decltype(lib.Send))bind("ncclSend");
+        lib.Recv = (decltype(lib.Recv))bind("ncclRecv");
+        lib.GetErrorString = (decltype(lib.GetErrorString))bind("ncclGetErrorString");
+        if (!ok)
+        {
+            snprintf(lib.why, sizeof lib.why, "the RCCL library lacks an entry point");
+            return;
+        }
+        lib.handle = handle;
+        published = &lib;
+    });
+    return published;
 }
 
 const char *rccl_why() { return "librccl.so.1 could not be loaded or lacks an entry point (multi-GPU needs RCCL)"; }
@@ -112,14 +120,16 @@ const char *rccl_why() { return "librccl.so.1 could not be loaded or lacks an en
             return dist_fail(TRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
-// rows of the rank-major, padded gather buffer -> frame order: one thread per double
-__global__ void assemble_rows_kernel(const double *gathered, const int *source_row, double *frame, long row_doubles, long total)
+// rows of the rank-major, padded gather buffer -> frame order: one thread per element (a double of the Screen layout, or a
+// byte of the emitter's (int)(c*255) triplets)
+template <class T>
+__global__ void assemble_rows_kernel(const T *gathered, const int *source_row, T *frame, long row_elements, long total)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total)
         return;
-    const long row = i / row_doubles, at = i - row * row_doubles;
-    frame[i] = gathered[(long)source_row[row] * row_doubles + at];
+    const long row = i / row_elements, at = i - row * row_elements;
+    frame[i] = gathered[(long)source_row[row] * row_elements + at];
 }
 
 struct Slot
@@ -129,6 +139,8 @@ struct Slot
     double *shard = nullptr;      // this rank's rows (padded to the largest shard); on the root a view into `gathered`
     double *gathered = nullptr;   // root: world x max_rows rows, rank-major
     double *frame = nullptr;      // root: height rows in frame order
+    // the same three for the frame as the emitter's bytes, 3 per pixel (trt_dist_enable_rgb8)
+    unsigned char *shard8 = nullptr, *gathered8 = nullptr, *frame8 = nullptr;
     hipEvent_t rendered = nullptr, consumed = nullptr;
     bool used = false;
 };
@@ -147,6 +159,8 @@ struct trt_dist
     ncclComm_t comm = nullptr;
     int *d_source_row = nullptr; // root: frame row -> row of the gather buffer
     bool through_comm = false;   // world > 1, or world == 1 with an id given: the gather path is taken (with no peers to receive from)
+    bool rgb8 = false;           // byte buffers allocated (trt_dist_enable_rgb8)
+    bool poisoned = false;       // a collective failed on this rank: its peers may have gone on without it, nothing can be trusted any more
     long calls = 0;
 };
 
@@ -223,6 +237,12 @@ extern "C" int trt_dist_destroy(trt_dist *d)
             (void)hipFree(s.shard);
         if (s.frame)
             (void)hipFree(s.frame);
+        if (s.gathered8)
+            (void)hipFree(s.gathered8);
+        else if (s.shard8)
+            (void)hipFree(s.shard8);
+        if (s.frame8)
+            (void)hipFree(s.frame8);
         if (s.ctx)
             (void)trt_destroy(s.ctx);
     }
@@ -348,61 +368,131 @@ extern "C" int trt_dist_set_scene(trt_dist *d, const Scene *scene)
     return TRT_OK;
 }
 
-extern "C" int trt_dist_render(trt_dist *d, const Camera *camera, int bounce_limit, int rays_per_pixel, void **d_frame)
+extern "C" int trt_dist_enable_rgb8(trt_dist *d)
+{
+    if (!d)
+        return dist_fail(TRT_ERR_ARGUMENT, "d is NULL");
+    if (d->rgb8)
+        return TRT_OK;
+    DIST_HIP(hipSetDevice(d->device));
+    const size_t row_bytes = (size_t)d->width * 3;
+    for (Slot &s : d->slots)
+    {
+        if (d->rank == d->root && d->through_comm)
+        {
+            DIST_HIP(hipMalloc((void **)&s.gathered8, (size_t)d->world * d->max_rows * row_bytes));
+            s.shard8 = s.gathered8 + (size_t)d->rank * d->max_rows * row_bytes;
+            DIST_HIP(hipMalloc((void **)&s.frame8, (size_t)d->height * row_bytes));
+        }
+        else
+            DIST_HIP(hipMalloc((void **)&s.shard8, (size_t)std::max(d->max_rows, 1) * row_bytes));
+    }
+    d->rgb8 = true;
+    return TRT_OK;
+}
+
+// One frame: this rank's rows on the next slot's stream, then the gather on the communicator's.  `bytes`: what travels, and
+// what the root assembles, are the emitter's (int)(c*255) triplets (TRT.c:1157-1163) instead of the doubles of the Screen layout.
+static int render_and_gather(trt_dist *d, const Camera *camera, int bounce_limit, int rays_per_pixel, bool bytes, void **d_frame)
 {
     if (!d || !camera)
         return dist_fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (d->poisoned)
+        return dist_fail(TRT_ERR_NOT_INITIALISED, "an earlier collective failed on this rank: destroy the trt_dist on every rank");
+    if (bytes && !d->rgb8)
+        return dist_fail(TRT_ERR_NOT_INITIALISED, "trt_dist_enable_rgb8 has not been called");
+    if (bounce_limit < 1 || rays_per_pixel < 1) // what trt_render_device would refuse: refuse it before anything is enqueued
+        return dist_fail(TRT_ERR_ARGUMENT, "bounce_limit %d / rays_per_pixel %d", bounce_limit, rays_per_pixel);
     DIST_HIP(hipSetDevice(d->device));
     Slot &s = d->slots[(size_t)(d->calls % (long)d->slots.size())];
-    d->calls++;
-    const size_t row_doubles = (size_t)d->width * 3;
+    const size_t row_doubles = (size_t)d->width * 3, row_elements = row_doubles; // 3 doubles or 3 bytes per pixel
+    // From here on a failure leaves this rank out of step with its peers (they will issue a collective this rank has skipped, or
+    // the other way round): the trt_dist is poisoned and every later call fails.
+    auto poison = [&](int rc) {
+        d->poisoned = true;
+        return rc;
+    };
     if (s.used && d->through_comm)
-        DIST_HIP(hipStreamWaitEvent(s.stream, s.consumed, 0)); // the slot's previous shard has left (or been assembled)
+        if (hipStreamWaitEvent(s.stream, s.consumed, 0) != hipSuccess) // the slot's previous shard has left (or been assembled)
+            return poison(dist_fail(TRT_ERR_HIP, "hipStreamWaitEvent failed"));
+    d->calls++;
     s.used = true;
     if (d->local_rows > 0)
     {
-        const int rc = trt_render_device(s.ctx, camera, &d->rows, bounce_limit, rays_per_pixel, s.shard,
-                                         (size_t)std::max(d->max_rows, 1) * row_doubles * sizeof(double));
+        int rc = trt_render_device(s.ctx, camera, &d->rows, bounce_limit, rays_per_pixel, s.shard,
+                                   (size_t)std::max(d->max_rows, 1) * row_doubles * sizeof(double));
+        if (!rc && bytes)
+            rc = trt_quantize_device(s.ctx, s.shard, (size_t)d->local_rows * d->width, s.shard8);
         if (rc)
-            return dist_fail(rc, "trt_render_device: %s", trt_last_error());
+            return poison(dist_fail(rc, "trt_render_device: %s", trt_last_error()));
     }
     if (!d->through_comm)
     {
         if (d_frame)
-            *d_frame = s.shard; // a single renderer's rows are the frame, in order; valid in stream order of the slot's stream
+            *d_frame = bytes ? (void *)s.shard8 : (void *)s.shard; // a single renderer's rows are the frame, in order; valid in stream order of the slot's stream
         return TRT_OK;
     }
     Rccl *R = rccl();
-    DIST_HIP(hipEventRecord(s.rendered, s.stream));
-    DIST_HIP(hipStreamWaitEvent(d->comm_stream, s.rendered, 0));
-    DIST_NCCL(R, R->GroupStart());
-    if (d->rank == d->root)
+    if (hipEventRecord(s.rendered, s.stream) != hipSuccess || hipStreamWaitEvent(d->comm_stream, s.rendered, 0) != hipSuccess)
+        return poison(dist_fail(TRT_ERR_HIP, "event hand-over to the communicator's stream failed"));
+    // the group is always closed, whatever happens inside it: the first error is kept and returned after ncclGroupEnd
+    ncclResult_t first = R->GroupStart();
+    const bool opened = first == ncclSuccess;
+    const ncclDataType_t type = bytes ? ncclUint8 : ncclDouble;
+    if (opened && d->rank == d->root)
     {
-        for (int r = 0; r < d->world; r++)
+        for (int r = 0; r < d->world && first == ncclSuccess; r++)
             if (r != d->root && d->rows_of_rank[(size_t)r] > 0)
-                DIST_NCCL(R, R->Recv(s.gathered + (size_t)r * d->max_rows * row_doubles, (size_t)d->rows_of_rank[(size_t)r] * row_doubles, ncclDouble, r,
-                                     d->comm, d->comm_stream));
+            {
+                const size_t at = (size_t)r * d->max_rows * row_elements, count = (size_t)d->rows_of_rank[(size_t)r] * row_elements;
+                first = R->Recv(bytes ? (void *)(s.gathered8 + at) : (void *)(s.gathered + at), count, type, r, d->comm, d->comm_stream);
+            }
     }
-    else if (d->local_rows > 0)
-        DIST_NCCL(R, R->Send(s.shard, (size_t)d->local_rows * row_doubles, ncclDouble, d->root, d->comm, d->comm_stream));
-    DIST_NCCL(R, R->GroupEnd());
+    else if (opened && d->local_rows > 0)
+        first = R->Send(bytes ? (const void *)s.shard8 : (const void *)s.shard, (size_t)d->local_rows * row_elements, type, d->root, d->comm, d->comm_stream);
+    if (opened)
+    {
+        const ncclResult_t closed = R->GroupEnd();
+        if (first == ncclSuccess)
+            first = closed;
+    }
+    if (first != ncclSuccess)
+        return poison(dist_fail(TRT_ERR_HIP, "the gather failed: %s", R->GetErrorString(first)));
     if (d->rank == d->root)
     {
-        const long total = (long)d->height * (long)row_doubles;
-        hipLaunchKernelGGL(assemble_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->comm_stream, (const double *)s.gathered,
-                           (const int *)d->d_source_row, s.frame, (long)row_doubles, total);
-        DIST_HIP(hipGetLastError());
+        const long total = (long)d->height * (long)row_elements;
+        if (bytes)
+            hipLaunchKernelGGL(assemble_rows_kernel<unsigned char>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->comm_stream,
+                               (const unsigned char *)s.gathered8, (const int *)d->d_source_row, s.frame8, (long)row_elements, total);
+        else
+            hipLaunchKernelGGL(assemble_rows_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->comm_stream,
+                               (const double *)s.gathered, (const int *)d->d_source_row, s.frame, (long)row_elements, total);
+        if (hipGetLastError() != hipSuccess)
+            return poison(dist_fail(TRT_ERR_HIP, "the assembly kernel could not be launched"));
     }
-    DIST_HIP(hipEventRecord(s.consumed, d->comm_stream));
+    if (hipEventRecord(s.consumed, d->comm_stream) != hipSuccess)
+        return poison(dist_fail(TRT_ERR_HIP, "hipEventRecord failed"));
     if (d_frame)
-        *d_frame = d->rank == d->root ? s.frame : nullptr;
+        *d_frame = d->rank == d->root ? (bytes ? (void *)s.frame8 : (void *)s.frame) : nullptr;
     return TRT_OK;
+}
+
+extern "C" int trt_dist_render(trt_dist *d, const Camera *camera, int bounce_limit, int rays_per_pixel, void **d_frame)
+{
+    return render_and_gather(d, camera, bounce_limit, rays_per_pixel, false, d_frame);
+}
+
+extern "C" int trt_dist_render_rgb8(trt_dist *d, const Camera *camera, int bounce_limit, int rays_per_pixel, void **d_frame_rgb8)
+{
+    return render_and_gather(d, camera, bounce_limit, rays_per_pixel, true, d_frame_rgb8);
 }
 
 extern "C" int trt_dist_synchronize(trt_dist *d)
 {
     if (!d)
         return dist_fail(TRT_ERR_ARGUMENT, "d is NULL");
+    if (d->poisoned)
+        return dist_fail(TRT_ERR_NOT_INITIALISED, "an earlier collective failed on this rank: destroy the trt_dist on every rank");
     DIST_HIP(hipSetDevice(d->device));
     for (Slot &s : d->slots)
         DIST_HIP(hipStreamSynchronize(s.stream));
@@ -436,6 +526,17 @@ extern "C" int trt_dist_fetch(trt_dist *d, const void *d_frame, Vector *pixels)
     if (rc)
         return rc;
     DIST_HIP(hipMemcpy(pixels, d_frame, (size_t)d->width * d->height * sizeof(Vector), hipMemcpyDeviceToHost));
+    return TRT_OK;
+}
+
+extern "C" int trt_dist_fetch_rgb8(trt_dist *d, const void *d_frame_rgb8, unsigned char *rgb)
+{
+    if (!d || !d_frame_rgb8 || !rgb)
+        return dist_fail(TRT_ERR_ARGUMENT, "NULL argument");
+    const int rc = trt_dist_synchronize(d);
+    if (rc)
+        return rc;
+    DIST_HIP(hipMemcpy(rgb, d_frame_rgb8, (size_t)d->width * d->height * 3, hipMemcpyDeviceToHost));
     return TRT_OK;
 }
 

@@ -47,6 +47,7 @@ _VP, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
 SYMBOLS = {
     "project_scene": (None, [C.POINTER(L.Scene), C.POINTER(L.Screen)]),
     "trt_render_frame": (_I, [C.POINTER(L.Scene), C.POINTER(L.Screen), _I, _I]),
+    "render_frame": (_I, [C.POINTER(L.Scene), C.POINTER(L.Screen), _I, _I]),
     "trt_render_frame_rgb8": (_I, [C.POINTER(L.Scene), _I, _I, _I, _I, _VP]),
     "trt_init": (_I, [_I]),
     "trt_shutdown": (_I, []),
@@ -94,6 +95,9 @@ SYMBOLS = {
     "trt_dist_set_scene": (_I, [_VP, C.POINTER(L.Scene)]),
     "trt_dist_render": (_I, [_VP, C.POINTER(L.Camera), _I, _I, C.POINTER(_VP)]),
     "trt_dist_synchronize": (_I, [_VP]),
+    "trt_dist_enable_rgb8": (_I, [_VP]),
+    "trt_dist_render_rgb8": (_I, [_VP, C.POINTER(L.Camera), _I, _I, C.POINTER(_VP)]),
+    "trt_dist_fetch_rgb8": (_I, [_VP, _VP, _VP]),
     "trt_dist_fetch": (_I, [_VP, _VP, _VP]),
     "trt_dist_source_rows": (_I, [_I, _I, _I, _I, C.POINTER(_I)]),
     "trt_dist_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
@@ -370,12 +374,12 @@ class Context:
         return obj, point, normal, material, lit
 
 
-def render_frame(scene_data, width, height, bounce_limit=10, rays_per_pixel=10):
-    """Host-in/host-out frame through the extended entry trt_render_frame (default context)."""
+def render_frame(scene_data, width, height, bounce_limit=10, rays_per_pixel=10, symbol="trt_render_frame"):
+    """Host-in/host-out frame through the extended entry trt_render_frame, or its alias render_frame (default context)."""
     from .scenes import new_screen
     scene = scene_data.as_scene()
     screen, pixels = new_screen(width, height)
-    _check(lib().trt_render_frame(C.byref(scene), C.byref(screen), bounce_limit, rays_per_pixel))
+    _check(getattr(lib(), symbol)(C.byref(scene), C.byref(screen), bounce_limit, rays_per_pixel))
     return pixels
 
 
@@ -443,6 +447,21 @@ class Dist:
     def fetch(self, device_frame):
         out = np.zeros((self.height, self.width, 3), dtype=np.float64)
         _dist_check(lib().trt_dist_fetch(self._h, _VP(device_frame), out.ctypes.data))
+        return out
+
+    def enable_rgb8(self):
+        """byte buffers for frames gathered as the emitter's (int)(c*255) triplets (trt_dist_enable_rgb8)"""
+        _dist_check(lib().trt_dist_enable_rgb8(self._h))
+
+    def render_rgb8(self, camera_array, bounce_limit, rays_per_pixel):
+        cam = camera_struct(camera_array)
+        out = _VP()
+        _dist_check(lib().trt_dist_render_rgb8(self._h, C.byref(cam), bounce_limit, rays_per_pixel, C.byref(out)))
+        return out.value
+
+    def fetch_rgb8(self, device_frame):
+        out = np.zeros((self.height, self.width, 3), dtype=np.uint8)
+        _dist_check(lib().trt_dist_fetch_rgb8(self._h, _VP(device_frame), out.ctypes.data))
         return out
 
     def close(self):

@@ -146,6 +146,9 @@ def test_drop_in_project_scene_symbol():
     case2 = next(c for c in SMALL if c["name"] == "demo_160x48_b10")
     px = hip.render_frame(T.golden_scene(case2), 160, 48, 10, 10)
     assert T.fnv(px) == case2["fb_fnv"]
+    # the entry under the name BASELINE.json's north_star gives it
+    px = hip.render_frame(T.golden_scene(case), 160, 48, 4, 10, symbol="render_frame")
+    assert T.fnv(px) == case["fb_fnv"]
     assert hip.lib().trt_shutdown() == 0
 
 
@@ -169,7 +172,10 @@ def test_baseline_configs_whole_frames_equal_reference_hash_and_oracle(ctx, name
     """BASELINE configs 2-5 at their FULL sizes (c3 is the frame bench.py times): every pixel of the production kernel's
     frame equals the all-core CPU oracle's frame bit for bit, the frame's FNV equals the hash the GENUINE reference
     produced for it (tests/golden/golden_full.json), the (int)(c*255) bytes likewise, the reference-order kernel -- an
-    independent HIP implementation -- agrees, and so do the trace_ray call counts."""
+    independent HIP implementation -- agrees, and so do the trace_ray call counts.  The counting instantiation of the kernel is
+    another binary than the one that ships (other register allocation): the frame is rendered once more WITHOUT counters -- the
+    instantiation bench.py times: <false, false, true> (shading decoupled) for c2 / c3 / c4,
+    <false, false, false, true> (a family per patch of a sphere) for c5 -- and must have the same bits."""
     import os
     case = T.golden_full()[name]
     w, h, b, spp = case["width"], case["height"], case["bounce_limit"], case["rays_per_pixel"]
@@ -183,6 +189,24 @@ def test_baseline_configs_whole_frames_equal_reference_hash_and_oracle(ctx, name
     assert T.fnv(fast) == case["fb_fnv"]
     assert T.fnv(T.oracle_rgb8(fast)) == case["rgb8_fnv"]
     assert counts == (case["path_rays"], case["shadow_rays"])
+    # counters off, the whole frame in ONE launch into device memory as bench.py renders it (trt_render_host splits a large frame
+    # into bands, which are too small for the decoupled kernel): the instantiation that is timed
+    import torch
+    fb = torch.zeros(h * w * 3, dtype=torch.float64, device="cuda:0")
+    ctx.set_kernel(hip.Context.PRODUCTION)
+    ctx.set_compaction(-1)
+    ctx.set_path_grids_min_spheres(12)  # the library's default (this module's context otherwise builds path tables for every scene)
+    try:
+        ctx.render_device(scene.camera, hip.RowSet.whole(w, h), b, spp, fb.data_ptr(), fb.numel() * 8)
+        ctx.synchronize()
+        shipped = fb.cpu().numpy().reshape(h, w, 3)
+        del fb
+        variant = ctx.render_variant()
+        n = len(scene.spheres)
+        assert variant["decoupled"] == (n < 128) and ctx.path_patches() == ((2, 24) if n == 256 else ((0, 1) if n >= 12 else (0, 0))), (variant, n)
+    finally:
+        ctx.set_path_grids_min_spheres(0)
+    assert np.array_equal(bits(shipped), bits(fast)) and T.fnv(shipped) == case["fb_fnv"]
     want, st = T.oracle_render(scene, w, h, b, spp, threads=min(os.cpu_count() or 1, 64))
     if not np.array_equal(bits(fast), bits(want)):
         bad = np.argwhere((bits(fast) != bits(want)).any(axis=2))
@@ -360,6 +384,93 @@ def test_c_host_drives_the_dist_renderer(tmp_path):
     scene = S.demo_scene(T.sky("colors"), cam)
     want, _ = T.oracle_render(scene, 160, 48, 10, 10)
     assert T.fnv(want) in out.stdout, out.stdout
+
+
+def build_rccl_stub():
+    """tests/rccl_stub.cpp -> tests/_build/librccl_stub.so (TEST INFRASTRUCTURE: several ranks on one GPU); None if it cannot be built"""
+    import os
+    import subprocess
+    build = os.path.join(T.ROOT, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    so, src = os.path.join(build, "librccl_stub.so"), os.path.join(T.ROOT, "tests", "rccl_stub.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        rc = subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", so, src,
+                             "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"], capture_output=True, text=True)
+        if rc.returncode != 0:
+            return None
+    return so
+
+
+@pytest.mark.parametrize("world,width,height,tile,depth,frames,rgb8",
+                         [(2, 160, 48, 8, 3, 7, 0), (3, 67, 13, 4, 3, 8, 0), (3, 1920, 1080, 8, 3, 7, 0), (2, 1920, 1080, 8, 2, 5, 1), (3, 160, 48, 4, 3, 7, 1)],
+                         ids=["2_ranks", "3_ranks_unequal_shards", "3_ranks_1080p", "2_ranks_1080p_rgb8", "3_ranks_rgb8"])
+def test_trt_dist_with_several_ranks_on_one_gpu(ctx, tmp_path, world, width, height, tile, depth, frames, rgb8):
+    """The C-ABI multi-GPU path (csrc/trt_dist.hip) EXECUTED by several ranks: `world` processes of the C host
+    examples/trt_dist_demo share this box's one GPU; the eight RCCL entry points the library binds by name come from the tests'
+    stand-in (tests/rccl_stub.cpp, selected by TRT_RCCL_LIB; real RCCL refuses two ranks on one device).  What runs here and
+    nowhere else on a one-GPU box: the peers' ncclSend branch, the root's ncclRecv offsets for ranks >= 1, shards of unequal
+    height (13 rows in tiles of 4 over 3 ranks: 5 / 4 / 4), slots re-used while a gather is outstanding (more frames than
+    slots), messages larger than the stand-in's staging slot, and the gather of the emitter's bytes (trt_dist_render_rgb8).
+    Rank 0's last frame must be the frame one renderer produces for that camera."""
+    import os
+    import subprocess
+    exe = os.path.join(T.ROOT, "examples", "trt_dist_demo")
+    stub = build_rccl_stub()
+    if not os.path.exists(exe) or stub is None:
+        pytest.skip("examples/trt_dist_demo or the RCCL stand-in not built")
+    sky = tmp_path / "colors"
+    sky.mkdir()
+    for f in T.FACES:
+        (sky / (f + ".ppm")).write_bytes(T.golden_ppm_raw("colors", f))
+    env = dict(os.environ, TRT_RCCL_LIB=stub, TRT_RCCL_STUB_SLOT_MB="8", TRT_RCCL_STUB_DEADLINE="60", GPU_MAX_HW_QUEUES="8")
+    procs = [subprocess.Popen([exe, str(sky), str(r), str(world), str(tmp_path / "id"), str(frames), str(width), str(height), str(tile), str(depth),
+                               "0", str(rgb8)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=240))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (r, err[-800:])
+    from terminalraytracer_amd import host
+    cam = host.orbit_camera((frames - 1) / 60.0, width, height)
+    scene = S.demo_scene(T.sky("colors"), cam)
+    if width * height <= 160 * 48:
+        want, _ = T.oracle_render(scene, width, height, 10, 10)
+    else:  # the single renderer's frame (itself checked against the oracle and the reference in the tests above)
+        want = render(ctx, scene, width, height, 10, 10)
+    fingerprint = T.fnv(T.oracle_rgb8(want)) if rgb8 else T.fnv(want)
+    assert f"{frames} frames {width}x{height} on {world} GPU(s)" in outs[0][0] and fingerprint in outs[0][0], (outs[0][0], fingerprint)
+
+
+def test_bench_two_ranks_through_the_c_abi_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), both ranks on this box's one
+    GPU: torch.distributed (gloo) only carries the communicator id and the timing; the frame goes through trt_dist_* over the
+    tests' stand-in for RCCL.  --check compares the gathered frame with a single renderer's, the timed frame is verified against
+    the reference's hash."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    stub = build_rccl_stub()
+    if stub is None:
+        pytest.skip("the RCCL stand-in could not be built")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, TRT_RCCL_LIB=stub, TRT_RCCL_STUB_DEADLINE="120")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--check", "--steps", "5",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=T.ROOT)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "CHECK sharded(2) == single: True" in out.stderr
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["verified"] is True and "trt_dist_*" in line["config"]["multi_gpu_path"] and \
+        "STAND-IN" in line["config"]["multi_gpu_path"], line["config"]
 
 
 def test_sharded_renderer_world_of_one(ctx):
