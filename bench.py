@@ -49,6 +49,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 WORKLOADS = {
     # name: (width, height, spheres, bounce limit, golden case of the frame at orbit time 1.0 / of animation frames)
+    "c2": dict(width=1920, height=1080, spheres=8, bounces=4, golden={1.0: "c2_1080p_8sph_b4"},
+               text="BASELINE configs[1]: 1920x1080, SYNTH-v0 8 spheres + checker floor, 2 lights, 4 bounces, 10 rays/pixel"),
+    "c4": dict(width=3840, height=2160, spheres=64, bounces=8, golden={1.0: "c4_2160p_64sph_b8"},
+               text="BASELINE configs[3] on ONE GPU: 3840x2160, SYNTH-v0 64 spheres + checker floor, 2 lights, 8 bounces, 10 rays/pixel"),
     "c3": dict(width=1920, height=1080, spheres=64, bounces=8, golden={1.0: "c3_1080p_64sph_b8"},
                text="BASELINE configs[2]: 1920x1080, SYNTH-v0 64 spheres seed 1234 + checker floor, 1 directional + 1 point light, "
                     "8 bounces, 10 rays/pixel, 256^2 procedural cubemap, off-screen f64 framebuffer"),
@@ -116,7 +120,7 @@ def cpu_baseline(scene, width, height, bounces, full_frame):
     _, st = T.oracle_render(scene, w, h, bounces, SPP, threads=threads)  # also yields the ray count of the sample
     dt_all = time.perf_counter() - t0
     ref = os.path.join(ROOT, "oracle", "_ref", f"libtrtref_b{bounces}_s{SPP}_w480_h280.so")
-    out = {"unit": "path rays/s", "cores": 1,
+    out = {"unit": "path rays/s", "cores": 1, "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
            "sample": f"1 {w}x{h} frame of the same scene/camera" + (" (the whole step)" if full_frame else " (1/16 of the step's pixels)")}
     if os.path.exists(ref):
         lib = C.CDLL(ref)
@@ -134,6 +138,110 @@ def cpu_baseline(scene, width, height, bounces, full_frame):
         out.update(kind="port", value=st.path_rays / dt, seconds=dt)
     out["port_all_cores"] = {"value": st.path_rays / dt_all, "cores": threads, "seconds": dt_all}
     out["path_rays_in_sample"] = st.path_rays
+    return out
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+FP64_PEAK_TFLOPS, FP64_PEAK_WITHOUT_FMA = 78.6, 39.3  # MI355X FP64 vector: half the 157.3 TFLOP/s FP32 vector figure of MI355X_MICROARCH.md
+
+
+def compute_executed(profile, kernel_ms):
+    """SURVEY 8d's bounding roofline, on EXECUTED work: FP64 wave instructions of one launch by class (COMMITTED rocprofv3 PMC
+    pass: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes, an FMA = 2 flops) over the render kernel's own duration measured in
+    THIS run.  frac is against the FMA peak; issue_frac is the share of the FP64 pipe's issue slots in use (an add or a multiply
+    takes the slot an FMA would: with -ffp-contract=off, which bit-exactness demands, most slots carry one flop)."""
+    if not profile or "flops_per_launch" not in profile:
+        return None
+    seconds = kernel_ms * 1e-3
+    achieved = profile["flops_per_launch"] / seconds / 1e12
+    return {"flops": profile["flops_per_launch"], "achieved_tflops": achieved, "peak": FP64_PEAK_TFLOPS, "peak_without_fma": FP64_PEAK_WITHOUT_FMA,
+            "frac": achieved / FP64_PEAK_TFLOPS, "frac_of_peak_without_fma": achieved / FP64_PEAK_WITHOUT_FMA,
+            "issue_frac": profile["fp64_lane_slots_per_launch"] / seconds / (FP64_PEAK_WITHOUT_FMA * 1e12),
+            "fp64_share_of_valu_instructions": profile["fp64_share_of_valu_instructions"], "kernel_ms": kernel_ms,
+            "basis": profile["basis"], "source": profile["source"]}
+
+
+def other_configs(hip, host, torch, local, depth, tile_rows):
+    """BASELINE configs 2, 4 (on one GPU) and 5 through the same calls and the same frames-in-flight loop as the headline, each
+    frame checked against the hash the GENUINE reference produced for it (tests/golden/golden_full.json): what the driver sees
+    of them.  Ray counts: the reference's own (golden_full.json) for the stills, the kernel's counting variant (untimed) for the
+    60 cameras of the orbit."""
+    out = {}
+    for name, steps, frames in (("c2", 12, 0), ("c4", 6, 0), ("c5", 60, 60)):
+        wl = WORKLOADS[name]
+        w, h, b = wl["width"], wl["height"], wl["bounces"]
+        scene = build_scene(name)
+        cams = animation_cameras(w, h, frames) if frames else [scene.camera]
+        t_setup = time.perf_counter()
+        d = hip.Dist(local, scene, None, 0, 1, w, h, tile_rows=tile_rows, frames_in_flight=depth)
+        setup_s = time.perf_counter() - t_setup
+        try:
+            if frames:
+                ctx0, rows = d.context(0), hip.RowSet.whole(w, h)
+                scratch = torch.zeros(h * w * 3, dtype=torch.float64, device=f"cuda:{local}")
+                ctx0.enable_counters(True)
+                path = []
+                for cam in cams:
+                    ctx0.render_device(cam, rows, b, SPP, scratch.data_ptr(), scratch.numel() * 8)
+                    path.append(ctx0.read_counters()[0])
+                ctx0.enable_counters(False)
+                del scratch
+            else:
+                path = [golden_hash(wl["golden"][1.0])["path_rays"]]
+            for i in range(3):
+                d.render(cams[i % len(cams)], b, SPP)
+            d.synchronize()
+            t0 = time.perf_counter()
+            last = None
+            for i in range(steps):
+                last = d.render(cams[i % len(cams)], b, SPP)
+            d.synchronize()
+            seconds = time.perf_counter() - t0
+            checks = []
+            probes = [((steps - 1) % len(cams), last)]
+            if frames and (steps - 1) % len(cams) != 0:
+                probes.append((0, None))
+            for index, frame in probes:
+                key = index if frames else 1.0
+                if key not in wl["golden"]:
+                    continue
+                if frame is None:
+                    frame = d.render(cams[index], b, SPP)
+                want = golden_hash(wl["golden"][key])
+                got = host.fnv1a64(d.fetch(frame))
+                checks.append({"frame": wl["golden"][key], "fnv": got, "reference_fnv": want["fb_fnv"], "ok": got == want["fb_fnv"]})
+            rays = float(sum(path[i % len(path)] for i in range(steps)))
+            variant = d.context(0).render_variant()
+            # strictly one frame at a time: the render kernel's own duration (HIP events on its stream)
+            ctx0, rows = d.context(0), hip.RowSet.whole(w, h)
+            scratch = torch.zeros(h * w * 3, dtype=torch.float64, device=f"cuda:{local}")
+            for i in range(6):
+                ctx0.render_device(cams[i % len(cams)], rows, b, SPP, scratch.data_ptr(), scratch.numel() * 8)
+                ctx0.synchronize()
+            render_ms = float(np.mean(ctx0.render_kernel_times(5)[0]))
+            del scratch
+            out[name] = {"workload": wl["text"], "steps": steps, "frames_in_flight": depth, "ms_per_frame": seconds / steps * 1e3,
+                         "frames_per_s": steps / seconds, "path_rays_per_s": rays / seconds, "path_rays_per_frame": rays / steps,
+                         "verified": bool(checks) and all(c["ok"] for c in checks), "verification": checks,
+                         "kernel": "render_rounds_kernel<false, false, %s%s>" % ("true" if variant["decoupled"] else "false",
+                                                                                  ", true" if d.context(0).path_patches()[0] else ""),
+                         "render_kernel_ms_one_at_a_time": render_ms, "scene_setup_s": setup_s}
+            prof = (committed_profile() or {}).get("config5") if name == "c5" else None
+            if prof:
+                out[name]["compute_executed"] = compute_executed(prof.get("compute_executed"), render_ms)
+                out[name]["valu"] = prof.get("valu")
+        finally:
+            d.close()
     return out
 
 
@@ -156,6 +264,7 @@ def main():
     ap.add_argument("--animation", type=int, default=0, metavar="F",
                     help="config 5: 256 spheres, 12 bounces, orbit cameras t = f/60 for f < F, a new camera every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2, 4 and 5 (rendered and verified after the headline on one GPU)")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed frame against the reference's hash")
     ap.add_argument("--kernel", type=int, default=0, help="0 production, 1 reference-order (debug)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals)")
@@ -395,6 +504,8 @@ def main():
                          "traffic_source": (prof or {}).get("source"),
                          "algorithmic_bytes": alg, "kernel": variant_name, "kernel_ms": render_ms_avg,
                          "achieved_by_step": alg / (ms_step * 1e-3) / 1e9,
+                         "traffic_over_algorithmic": ((prof or {}).get("hbm_bytes_per_launch") or 0) / alg if prof else None,
+                         "compute_executed": compute_executed((prof or {}).get("compute_executed"), render_ms_avg),
                          "note": "achieved = algorithmic bytes of a frame (SURVEY 8d) / the render kernel's own average duration, HIP events "
                                  "on its stream, frames launched strictly one at a time (one_frame_at_a_time); the timed region keeps "
                                  "frames_in_flight frames in flight, so consecutive launches overlap there.  The path is VALU-issue-bound: "
@@ -407,7 +518,7 @@ def main():
             "compute": {"basis": "reference-equivalent FP64 flops = trace_ray calls x (25 N + 17)",
                         "flops_per_frame": (path_mean + float(np.mean(shadow_cam))) * (25 * wl["spheres"] + 17),
                         "achieved": (path_mean + float(np.mean(shadow_cam))) * (25 * wl["spheres"] + 17) / (render_ms_avg * 1e-3) / 1e12,
-                        "unit": "TFLOP/s", "peak": 78.6, "peak_without_fma": 39.3,
+                        "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS, "peak_without_fma": FP64_PEAK_WITHOUT_FMA,
                         "peak_source": "MI355X FP64 vector: half the 157.3 TFLOP/s FP32 vector figure of MI355X_MICROARCH.md; -ffp-contract=off halves it again"},
             "valu": (prof or {}).get("valu"),
             "kernel_info": ctx0.kernel_info(),
@@ -417,6 +528,13 @@ def main():
                                 exact_test_rounds_per_trace=diag["phase2_rounds"] / max(1, path_per_cam[0] + shadow_per_cam[0]) * 64)
             if args.kernel == 0 else diag,
         }
+        if world == 1 and workload == "c3" and not args.no_configs and args.kernel == 0 and args.sky_dim == SKY_DIM:
+            r.close()  # the headline's buffers make room
+            r = None
+            try:
+                out["configs"] = other_configs(hip, host, torch, local, args.depth, args.tile_rows)
+            except Exception as e:  # never lose the headline over the rest
+                out["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(scene, width, height, bounces, full_frame=(workload == "c3"))
@@ -424,7 +542,12 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "path rays/s", "cores": 1, "kind": "port", "sample": "not measured",
                                        "error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
-    r.close()
+        configs = out.get("configs") or {}
+        if any(isinstance(c, dict) and c.get("verified") is False for c in configs.values()):
+            verified = False
+            checks = checks + [v for c in configs.values() if isinstance(c, dict) for v in c.get("verification", []) if not v["ok"]]
+    if r is not None:
+        r.close()
     if world > 1:
         dist.destroy_process_group()
     if rank == 0 and verified is False:

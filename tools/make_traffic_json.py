@@ -1,11 +1,30 @@
 """profiles/traffic.json from a PMC summary (tools/pmc_summary.py --json) of `bench.py --depth 1`:
 HBM bytes per launch (FETCH_SIZE / WRITE_SIZE from separate passes, gfx950 correction of MI355X_MICROARCH.md applied) and the
-VALU counters.  usage: python tools/make_traffic_json.py <pmc_summary.json> <tag> > profiles/traffic.json"""
+VALU counters.  The FP64 instruction counters (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64) give the EXECUTED FP64 work of a launch, for config 3 and,
+from a second summary, for config 5.
+usage: python tools/make_traffic_json.py <pmc_summary.json> <tag> [<c5_pmc_summary.json>] [<round dir, default r03>] > profiles/traffic.json"""
 import json
 import sys
 
 s = json.load(open(sys.argv[1]))
 tag = sys.argv[2]
+c5 = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
+rnd = sys.argv[4] if len(sys.argv) > 4 else "r03"
+
+
+def executed_fp64(counters, kernel_name, where):
+    """FP64 work the hardware EXECUTED in one launch: wave-level instructions by class x 64 lanes (a wave instruction occupies the
+    FP64 pipe for all 64 lanes whatever its exec mask), an FMA counted as two flops."""
+    add, mul, fma, trans = (counters[k]["mean"] for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+    valu = counters["SQ_INSTS_VALU"]["mean"]
+    f32 = sum(counters[k]["mean"] for k in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32") if k in counters)
+    return {"source": where + ", " + kernel_name.replace("trt::", "") + ", means over the dispatches",
+            "wave_instructions": {"add_f64": add, "mul_f64": mul, "fma_f64": fma, "trans_f64": trans, "all_valu": valu, "add_mul_fma_f32": f32},
+            "fp64_share_of_valu_instructions": (add + mul + fma + trans) / valu,
+            "flops_per_launch": 64.0 * (add + mul + trans) + 128.0 * fma,
+            "fp64_lane_slots_per_launch": 64.0 * (add + mul + fma + trans),
+            "basis": "issued: 64 lanes per wave instruction, FMA = 2 flops; x lane_activity for the flops of active lanes only"}
+
 rk = next(k for k in s if "render_rounds_kernel<false" in k)
 dk = next(k for k in s if "reduce_samples_kernel" in k)
 R, D = s[rk], s[dk]
@@ -17,7 +36,7 @@ total = render_w + 2 * render_f + reduce_w + 2 * reduce_f
 gui = m(R, "GRBM_GUI_ACTIVE") / 8.0
 out = {
     "workload": "bench.py default (1920x1080, 64 spheres, 8 bounces, 10 rays/pixel), production kernels " + rk.replace("trt::", "") + " + reduce_samples_kernel, --depth 1",
-    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace; profiles/r02/{tag}_pmc_summary.txt (tools/profile_round.sh); means over the dispatches",
+    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace; profiles/{rnd}/{tag}_pmc_summary.txt (tools/profile_round.sh); means over the dispatches",
     "per_launch_KB": {"render_rounds_kernel": {"FETCH_SIZE": m(R, "FETCH_SIZE"), "WRITE_SIZE": m(R, "WRITE_SIZE")},
                       "reduce_samples_kernel": {"FETCH_SIZE": m(D, "FETCH_SIZE"), "WRITE_SIZE": m(D, "WRITE_SIZE")}},
     "correction": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced streaming read: the reduce kernel streams the 497.7 MB scratch "
@@ -31,7 +50,7 @@ out = {
             "the per-pixel mean is formed in the reference's order. It costs 0.10 ms (reduce kernel) of a 2.0 ms frame. The candidate tables (7 MB of list cells at 64 spheres) are "
             "read once per trace with 8-byte loads. The frame is bound by VALU issue and dependent-load latency, not by HBM.",
     "valu": {
-        "source": f"profiles/r02/{tag}_pmc_summary.txt (rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE), " + rk.replace("trt::", "") + ", means over the dispatches",
+        "source": f"profiles/{rnd}/{tag}_pmc_summary.txt (rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE), " + rk.replace("trt::", "") + ", means over the dispatches",
         "SQ_INSTS_VALU_per_launch": m(R, "SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU": m(R, "SQ_ACTIVE_INST_VALU"), "SQ_WAVES": m(R, "SQ_WAVES"), "simds": 1024,
         "GRBM_GUI_ACTIVE_per_xcd": gui,
         "valu_busy_measured": 4.0 * m(R, "SQ_ACTIVE_INST_VALU") / (1024 * gui),
@@ -41,4 +60,17 @@ out = {
         "wave_cycles_waiting_inst_frac": m(R, "SQ_WAIT_INST_ANY") / m(R, "SQ_WAVE_CYCLES"),
     },
 }
+if "SQ_INSTS_VALU_FMA_F64" in R:
+    out["compute_executed"] = executed_fp64(R, rk, f"profiles/{rnd}/{tag}_pmc_summary.txt (rocprofv3 --pmc SQ_INSTS_VALU_*_F64)")
+if c5:
+    ck = next(k for k in c5 if "render_rounds_kernel<false" in k)
+    C = c5[ck]
+    gui5 = m(C, "GRBM_GUI_ACTIVE") / 8.0
+    out["config5"] = {
+        "workload": "bench.py --animation 60 --depth 1 (1920x1080, 256 spheres, 12 bounces, orbit), " + ck.replace("trt::", ""),
+        "valu": {"SQ_INSTS_VALU_per_launch": m(C, "SQ_INSTS_VALU"), "valu_busy_measured": 4.0 * m(C, "SQ_ACTIVE_INST_VALU") / (1024 * gui5),
+                 "lane_activity": m(C, "SQ_THREAD_CYCLES_VALU") / (64.0 * m(C, "SQ_ACTIVE_INST_VALU")),
+                 "source": f"profiles/{rnd}/{tag}_c5_pmc_summary.txt"},
+        "compute_executed": executed_fp64(C, ck, f"profiles/{rnd}/{tag}_c5_pmc_summary.txt"),
+    }
 print(json.dumps(out, indent=1))
