@@ -1354,11 +1354,13 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         else
             hipLaunchKernelGGL((trt::render_rounds_kernel<false>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         HIP_TRY(hipEventRecord(ctx->ev_mid[slot], stream));
+#if !TRT_AB_SKIP_REDUCE // diagnostic build (profiles/r03: what the ordered mean's streaming pass costs in the pipelined loop)
         { // TRT.c:1063-1065: the mean over each pixel's samples, in sample order
             const long values = pixels * 3;
             hipLaunchKernelGGL(trt::reduce_samples_kernel, dim3((unsigned)((values + 255) / 256)), dim3(256), 0, stream,
                                (const double *)scratch.ptr, (double *)d_pixels, values, rays_per_pixel, f.inv_spp);
         }
+#endif
         HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
     }
     HIP_TRY(hipGetLastError());

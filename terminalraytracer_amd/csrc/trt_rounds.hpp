@@ -1047,6 +1047,9 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
                 {
                     TRT_FRESH_ARGS;
                     unsigned slot = slot_id;
+#if TRT_AB_DUMMY_STORES // diagnostic build (profiles/r03: what the sample scratch costs): every store lands in 48 KB
+                    slot &= 2047u;
+#endif
                     asm volatile("" : "+v"(slot)); // the address is formed here, not kept as 64 bits for the life of the sample
                     double *out = f.samples + (size_t)slot * 3;
                     out[0] = sample.x * q;
@@ -1157,7 +1160,11 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
             if (end_sample)
             {
                 TRT_FRESH_ARGS;
+#if TRT_AB_DUMMY_STORES
+                double *out = f.samples + (size_t)(slot_id & 2047u) * 3;
+#else
                 double *out = f.samples + (size_t)slot_id * 3;
+#endif
                 out[0] = sample.x * q; // plain stores: non-temporal ones (keeping the 498 MB stream out of L2) measured no different
                 out[1] = sample.y * q;
                 out[2] = sample.z * q;
