@@ -1,6 +1,9 @@
 """Randomised parity campaign on the GPU box: many fuzzed scenes (tests/test_gpu_parity._fuzz_scene: 0..100 spheres, exact ties,
 degenerate radii, lights on sphere surfaces, cameras inside spheres, tilted grounds) rendered by the production kernel and
-compared bit for bit with the oracle.  usage: python tools/fuzz_campaign.py [first_seed] [count]"""
+compared bit for bit with the oracle.  usage: python tools/fuzz_campaign.py [first_seed] [count] [mode]
+modes: "" generic | wide | lights | compact (decoupled shading forced on) | refract (extension, against its own restatement) |
+patches / patches_refract: a family per PATCH of a sphere's surface (trt_set_path_patches 1..4, random table resolutions, the
+three scene generators in turn), tables for every scene."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -55,7 +58,8 @@ def light_heavy_scene(rng, w, h):
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
 make = {"wide": wide_scene, "lights": light_heavy_scene, "compact": light_heavy_scene}.get(mode, P._fuzz_scene)
-refract = mode == "refract"  # EXTENSION, parity unpinned: against the oracle's restatement of the extension, not the reference
+patches = mode.startswith("patches")
+refract = mode in ("refract", "patches_refract")  # EXTENSION, parity unpinned: against the oracle's restatement of the extension, not the reference
 bad = 0
 with hip.Context(0) as ctx:
     kernel = P.COMPACT if mode == "compact" else hip.Context.PRODUCTION  # "compact": the decoupled shading (trt_set_compaction) forced on
@@ -65,7 +69,13 @@ with hip.Context(0) as ctx:
         b, spp = int(rng.integers(1, 13)), int(rng.choice([1, 3, 10]))
         if mode == "compact" and seed % 3 == 0:
             b = 1  # every hit ends its sample: the ring is flushed in every round
-        scene = make(rng, w, h)
+        if patches:
+            scene = (P._fuzz_scene, wide_scene, light_heavy_scene)[seed % 3](rng, w, h)
+            ctx.set_path_grids_min_spheres(0)
+            ctx.set_path_patches(int(rng.integers(1, 5)))
+            ctx.set_path_grids(int(rng.choice([16, 64])), int(rng.choice([3, 8, 16])))
+        else:
+            scene = make(rng, w, h)
         ior = None
         if refract and len(scene.spheres):
             ior = rng.choice([0.0, 0.0, 1.5, 1.33, 2.4, 1.0, 0.7], len(scene.spheres))

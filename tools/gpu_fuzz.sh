@@ -1,8 +1,12 @@
+#!/bin/bash
+# Randomised parity campaigns on the GPU box (tools/fuzz_campaign.py): scenes x modes as arguments "first count mode" ...
+# usage: gpurun -- bash tools/gpu_fuzz.sh "100000 5000" "120000 2500 wide" "300000 3000 patches" ...
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2f
-(timeout -k 10 300 python3 tools/fuzz_campaign.py 100000 5000 2>&1 | tail -3
-timeout -k 10 250 python3 tools/fuzz_campaign.py 120000 2500 wide 2>&1 | tail -3
-timeout -k 10 250 python3 tools/fuzz_campaign.py 140000 2500 lights 2>&1 | tail -3
-timeout -k 10 250 python3 tools/fuzz_campaign.py 160000 3000 refract 2>&1 | tail -3
-timeout -k 10 120 python3 tools/extremes.py 2>&1 | tail -10) | tee gpurun_out/r2f/fuzz2.txt
+mkdir -p gpurun_out/fuzz
+for job in "$@"; do
+  echo "== fuzz_campaign.py $job"
+  timeout -k 10 400 python3 tools/fuzz_campaign.py $job 2>&1 | grep -v "^\.\.\. " | tail -6
+done | tee gpurun_out/fuzz/fuzz.txt
+grep -q MISMATCH gpurun_out/fuzz/fuzz.txt && exit 1
+exit 0
