@@ -13,7 +13,7 @@ empty :=
 space := $(empty) $(empty)
 TAG := $(subst $(space),,$(subst =,_,$(subst -D,_,$(TUNE))))
 HIPFLAGS := $(TUNE) --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -std=c++17 \
-            -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+            -Iinclude -I$(CSRC) -Wall -Wno-unused-function $(EXTRA)
 HOSTFLAGS := -O2 -ffp-contract=off -fno-fast-math -fPIC -std=c11 -Iinclude -Wall -Wextra
 HOST_SRC := $(wildcard $(CSRC)/host/*.c)
 HOST_OBJ := $(patsubst $(CSRC)/host/%.c,$(BUILD)/host_%.o,$(HOST_SRC))
