@@ -473,7 +473,8 @@ def main():
         path_mean = float(np.mean(path_cam))
         prof = committed_profile() if (world == 1 and workload == "c3") else None
         variant = ctx0.render_variant()  # the shading decoupled from the owning lane or the plain rounds
-        variant_name = "render_rounds_kernel<false, false, %s>" % ("true" if variant["decoupled"] else "false")
+        variant_name = "render_rounds_kernel<false, false, %s%s>" % ("true" if variant["decoupled"] else "false",
+                                                                    ", true" if ctx0.path_patches()[0] else "")
         out = {
             "metric": "path rays/s (primary+secondary) at 1920x1080, 64 spheres, 8 bounces" if workload == "c3" else
                       "path rays/s (primary+secondary) at 1920x1080, 256 spheres, 12 bounces, orbiting camera",
