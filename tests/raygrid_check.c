@@ -319,3 +319,53 @@ long raygrid_host_cells(const double *spheres, int n, const double *ground, cons
     destroy(T);
     return used;
 }
+
+/* The patches of trt_patchset_init: `samples` pseudo-random points of the unit sphere (and points pushed onto the patches' edges,
+ * the cube map's edges and corners), each looked up exactly as the kernel does (trt_patch_of, FP32); returns the largest
+ * |u - t_k| / rho_k met (must be <= 1: the patch's ball holds every point that is looked up in it) and, in *worst_rho, the largest
+ * rho_k.  Also checks that every patch index in [0, count) occurs. */
+double raygrid_patch_cover(int m, long samples, double *worst_rho, int *patches_seen)
+{
+    trt_patchset P;
+    trt_patchset_init(&P, m);
+    unsigned char seen[TRT_PATCH_MAX];
+    memset(seen, 0, sizeof seen);
+    double worst = 0.0;
+    *worst_rho = 0.0;
+    for (int k = 0; k < P.count; k++)
+        *worst_rho = P.rec[k][3] > *worst_rho ? P.rec[k][3] : *worst_rho;
+    unsigned long long s = 0x9E3779B97F4A7C15ull;
+    for (long n = 0; n < samples; n++)
+    {
+        double u[3];
+        for (int a = 0; a < 3; a++)
+        {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            u[a] = (double)(long long)(s >> 11) * 0x1p-52 - 1.0; /* [-1, 1) */
+        }
+        if (n % 5 == 1 && m) /* onto an edge between two patches of a face */
+            u[(n / 5) % 3] = u[((n / 5) + 1) % 3] * (double)((n / 15) % (2 * m + 1) - m) / (double)m;
+        if (n % 5 == 2) /* onto a cube edge: two coordinates of equal magnitude */
+            u[(n / 5) % 3] = (n & 64 ? -1.0 : 1.0) * u[((n / 5) + 1) % 3];
+        if (n % 5 == 3) /* near a cube corner */
+            u[0] = (n & 64 ? -1.0 : 1.0) * u[2] * (1.0 + 1e-9 * (double)(n % 7)), u[1] = (n & 128 ? -1.0 : 1.0) * u[2];
+        const double len = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (!(len > 1e-3))
+            continue;
+        for (int a = 0; a < 3; a++)
+            u[a] /= len;
+        /* the kernel looks the patch up from o - c = |r| u with any |r|: the look-up only sees ratios */
+        const double radius = 0.1 + (double)(n % 97);
+        const int k = trt_patch_of(m, radius * u[0], radius * u[1], radius * u[2]);
+        if (k < 0 || k >= P.count)
+            return 1e9;
+        seen[k] = 1;
+        const double e[3] = {u[0] - P.rec[k][0], u[1] - P.rec[k][1], u[2] - P.rec[k][2]};
+        const double ratio = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) / P.rec[k][3];
+        worst = ratio > worst ? ratio : worst;
+    }
+    *patches_seen = 0;
+    for (int k = 0; k < P.count; k++)
+        *patches_seen += seen[k];
+    return worst;
+}

@@ -94,6 +94,21 @@ def test_path_tables_hold_every_exact_hit_on_real_frames(checker, name, make, w,
                 assert st.members >= whole.members - 8 and st.candidates < whole.candidates
 
 
+@pytest.mark.parametrize("m", [0, 1, 2, 3, 4])
+def test_every_point_of_a_patch_lies_in_the_patch_s_ball(checker, m):
+    """trt_patchset_init (csrc/trt_raygrid.h): a ray that starts on patch k of a sphere is a member of the patch's family because its
+    origin lies within |r| rho_k of the apex c + |r| t_k.  Two million points of the unit sphere -- a fifth of them pushed onto the
+    edges between patches, a fifth onto the cube map's edges, a fifth next to its corners -- looked up as the kernel looks them up
+    (trt_patch_of, FP32): none is farther than rho_k from t_k, every patch occurs, and rho is what DESIGN.md says it is."""
+    checker.raygrid_patch_cover.argtypes = [C.c_int, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    checker.raygrid_patch_cover.restype = C.c_double
+    rho, seen = C.c_double(), C.c_int()
+    worst = checker.raygrid_patch_cover(m, 2_000_000, C.byref(rho), C.byref(seen))
+    print(f"\nm {m}: largest |u - t_k| / rho_k {worst:.6f}, largest rho {rho.value:.4f}, patches seen {seen.value}")
+    assert worst <= 1.0 and seen.value == (6 * m * m if m else 1)
+    assert abs(rho.value - {0: 1.0, 1: 0.8168, 2: 0.5164, 3: 0.4402, 4: 0.3281}[m]) < 2e-3
+
+
 def test_any_family_a_ray_is_a_member_of_is_conservative_for_it(checker):
     """the structural assignment of families is a convenience: the membership test alone must make a table safe"""
     scene = S.synth_scene(64, T.sky("synth"), T.bench_camera(64, 36, 2.5))
