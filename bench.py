@@ -491,7 +491,9 @@ def main():
                        "kernel": {0: "persistent waves, synchronous rounds" + (", shading decoupled from the owning lane" if variant["decoupled"] else ""),
                                   1: "reference-order"}[args.kernel],
                        "workgroup_threads": variant["workgroup_threads"],
-                       "frames_in_flight": args.depth, "reserved_cus": args.reserve_cus},
+                       "frames_in_flight": args.depth, "reserved_cus": args.reserve_cus,
+                       "camera": "static: the eye's two candidate tables are built once, before the timed region (an orbit rebuilds them every "
+                                 "frame, ~0.06 ms: see configs.c5)" if args.animation == 0 else "a new camera every frame (the eye's tables are rebuilt per frame, inside the timed region)"},
             "frames_per_s": args.steps / seconds,
             "rays_per_frame": {"path": path_mean, "shadow": float(np.mean(shadow_cam))},
             "all_rays_per_s": (path_timed + shadow_timed) / seconds,
