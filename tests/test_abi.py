@@ -106,3 +106,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         monkeypatch.undo()
         hip.lib.cache_clear()
         hip.lib()
+
+
+def test_rccl_is_bound_by_name_and_may_be_overridden_for_tests(tmp_path):
+    """csrc/trt_dist.hip binds its eight RCCL entry points at run time; TRT_RCCL_LIB names another library with the same entry
+    points (the tests' stand-in for several ranks on one GPU, tests/rccl_stub.cpp) and is honoured strictly: a library that cannot
+    be loaded is an error, not a reason to fall back to librccl.  No GPU is needed to make an id."""
+    import subprocess
+    import sys
+    stub = os.path.join(T.ROOT, "tests", "_build", "librccl_stub.so")
+    if not os.path.exists(stub):
+        rc = subprocess.run(["make", "-C", T.ROOT, "stub"], capture_output=True, text=True)
+        if rc.returncode != 0 or not os.path.exists(stub):
+            pytest.skip("the RCCL stand-in could not be built here")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from terminalraytracer_amd import hip\n"
+            "try:\n    print('ID', hip.dist_unique_id()[:15])\nexcept hip.TrtError as e:\n    print('ERR', e.code)\n") % T.ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, TRT_RCCL_LIB=stub), timeout=120)
+    assert "ID b'/trt_rccl_stub_" in out.stdout, (out.stdout, out.stderr[-300:])
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         env=dict(os.environ, TRT_RCCL_LIB=str(tmp_path / "no_such_library.so")), timeout=120)
+    assert "ERR -5" in out.stdout, (out.stdout, out.stderr[-300:])

@@ -359,6 +359,20 @@ def test_c_abi_dist_renderer_world_of_one(ctx, through_rccl):
         assert d.context(0).kernel_info()["compute_units"] >= 8
         with pytest.raises(IndexError):
             d.context(3)
+        # the same frames as the emitter's bytes (trt_dist_render_rgb8): not before the byte buffers exist, then interleaved with
+        # f64 frames on the same slots; bad arguments are refused before anything is enqueued and leave the trt_dist usable
+        with pytest.raises(hip.TrtError):
+            d.render_rgb8(scene.camera, 8, 10)
+        d.enable_rgb8()
+        d.enable_rgb8()  # idempotent
+        with pytest.raises(hip.TrtError):
+            d.render(scene.camera, 0, 10)
+        for t in (0.0, 2.5):
+            cam = T.bench_camera(128, 72, t)
+            rgb = d.fetch_rgb8(d.render_rgb8(cam, 8, 10))
+            f64 = d.fetch(d.render(cam, 8, 10))
+            want, _ = T.oracle_render(scene.with_camera(cam), 128, 72, 8, 10)
+            assert np.array_equal(bits(f64), bits(want)) and np.array_equal(rgb, T.oracle_rgb8(want)), t
     with pytest.raises(hip.TrtError):
         hip.Dist(0, scene, None, 0, 2, 128, 72)  # more than one rank needs the communicator's id
 
