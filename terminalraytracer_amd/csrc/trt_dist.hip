@@ -67,12 +67,14 @@ struct Rccl
 // Bound once, by whichever thread comes first (one rank may be one THREAD per GPU: trt_hip.h); the struct is published only
 // after every symbol is bound.  TRT_RCCL_LIB names another library with the same eight entry points (the tests' stand-in
 // that lets several ranks share one GPU, tests/rccl_stub.cpp); the product never sets it.
+Rccl g_rccl; // written inside the call_once below, read-only afterwards
+
 Rccl *rccl()
 {
-    static Rccl lib;
+    Rccl &lib = g_rccl;
     static Rccl *published = nullptr;
     static std::once_flag once;
-    std::call_once(once, [] {
+    std::call_once(once, [&lib] {
         const char *override_name = getenv("TRT_RCCL_LIB");
         const char *names[] = {override_name && *override_name ? override_name : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         const int count = override_name && *override_name ? 1 : 3; // an override that cannot be loaded is an error, not a reason to look elsewhere
@@ -110,7 +112,14 @@ Rccl *rccl()
     return published;
 }
 
-const char *rccl_why() { return "librccl.so.1 could not be loaded or lacks an entry point (multi-GPU needs RCCL)"; }
+// after rccl() has returned nullptr: why
+const char *rccl_why()
+{
+    static thread_local char text[400];
+    snprintf(text, sizeof text, "the RCCL library could not be bound (multi-GPU needs librccl.so.1, or the library TRT_RCCL_LIB names): %s",
+             g_rccl.why[0] ? g_rccl.why : "unknown reason");
+    return text;
+}
 
 #define DIST_NCCL(R, expr)                                                                                          \
     do                                                                                                              \
@@ -377,14 +386,16 @@ extern "C" int trt_dist_enable_rgb8(trt_dist *d)
     DIST_HIP(hipSetDevice(d->device));
     const size_t row_bytes = (size_t)d->width * 3;
     for (Slot &s : d->slots)
-    {
+    { // a call that failed half-way may be repeated: what exists is kept
         if (d->rank == d->root && d->through_comm)
         {
-            DIST_HIP(hipMalloc((void **)&s.gathered8, (size_t)d->world * d->max_rows * row_bytes));
+            if (!s.gathered8)
+                DIST_HIP(hipMalloc((void **)&s.gathered8, (size_t)d->world * d->max_rows * row_bytes));
             s.shard8 = s.gathered8 + (size_t)d->rank * d->max_rows * row_bytes;
-            DIST_HIP(hipMalloc((void **)&s.frame8, (size_t)d->height * row_bytes));
+            if (!s.frame8)
+                DIST_HIP(hipMalloc((void **)&s.frame8, (size_t)d->height * row_bytes));
         }
-        else
+        else if (!s.shard8)
             DIST_HIP(hipMalloc((void **)&s.shard8, (size_t)std::max(d->max_rows, 1) * row_bytes));
     }
     d->rgb8 = true;
