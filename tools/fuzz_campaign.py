@@ -2,6 +2,7 @@
 degenerate radii, lights on sphere surfaces, cameras inside spheres, tilted grounds) rendered by the production kernel and
 compared bit for bit with the oracle.  usage: python tools/fuzz_campaign.py [first_seed] [count] [mode]
 modes: "" generic | wide | lights | compact (decoupled shading forced on) | refract (extension, against its own restatement) |
+dense: 128..256 spheres packed tightly, the library's default patches (or 6 / 54 / 96) |
 patches / patches_refract: a family per PATCH of a sphere's surface (trt_set_path_patches 1..4, random table resolutions, the
 three scene generators in turn), tables for every scene."""
 import os, sys
@@ -55,9 +56,32 @@ def light_heavy_scene(rng, w, h):
     return S.SceneData(scene.spheres, scene.ground, dl.reshape(-1, 6), pl.reshape(-1, 7), scene.camera, scene.sky)
 
 
+def dense_scene(rng, w, h):
+    """128..256 spheres packed like SYNTH-v0 or tighter (the config-5 regime: long candidate lists, every table with patches),
+    mirrors among them, a tilted or a plain ground, the camera inside or outside the cloud."""
+    n = int(rng.integers(128, 257))
+    box = rng.uniform(1.5, 5.0)
+    sph = np.zeros((n, 9))
+    sph[:, :3] = rng.uniform(-1, 1, (n, 3)) * [box, box * 0.5, box] + [0.0, 0.5, 0.0]
+    sph[:, 3] = rng.uniform(0.05, 0.5, n) * rng.choice([0.5, 1.0, 1.5])
+    sph[:, 4:7] = rng.uniform(0, 1, (n, 3))
+    sph[:, 7] = rng.choice([0.0, 0.3, 0.8, 1.0], n)
+    sph[:, 8] = 100.0
+    ground = S.demo_ground().copy()
+    if rng.integers(0, 3) == 0:
+        ground[3:6] = [rng.normal() * 0.2, 1.0, rng.normal() * 0.2]
+    ground[9] = rng.choice([0.0, 0.2, 0.9])
+    d, p = S.demo_lights()
+    if rng.integers(0, 2):
+        p = np.concatenate([p, [[box, 2.0, -box, 1.0, 0.8, 0.6, 20.0]]])
+    cam = T.bench_camera(w, h, float(rng.choice([0.0, 0.5, 1.0, 2.5, 10.0])))
+    cam[9:12] *= rng.uniform(0.2, 2.0)
+    return S.SceneData(sph, ground, d, p, cam, T.sky("synth"))
+
+
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
-make = {"wide": wide_scene, "lights": light_heavy_scene, "compact": light_heavy_scene}.get(mode, P._fuzz_scene)
+make = {"wide": wide_scene, "lights": light_heavy_scene, "compact": light_heavy_scene, "dense": dense_scene}.get(mode, P._fuzz_scene)
 patches = mode.startswith("patches")
 refract = mode in ("refract", "patches_refract")  # EXTENSION, parity unpinned: against the oracle's restatement of the extension, not the reference
 bad = 0
@@ -67,6 +91,10 @@ with hip.Context(0) as ctx:
         rng = np.random.default_rng(seed)
         w, h = int(rng.integers(8, 160)), int(rng.integers(4, 90))
         b, spp = int(rng.integers(1, 13)), int(rng.choice([1, 3, 10]))
+        if mode == "dense":  # the library's defaults (24 patches from 128 spheres up) two times in three, else 6 / 54 / 96 patches
+            w, h, spp = min(w, 96), min(h, 54), int(rng.choice([1, 3]))
+            ctx.set_path_patches(-1 if seed % 3 else int(rng.choice([1, 3, 4])))
+            ctx.set_path_grids(64, 32 if seed % 3 else 8)
         if mode == "compact" and seed % 3 == 0:
             b = 1  # every hit ends its sample: the ring is flushed in every round
         if patches:
