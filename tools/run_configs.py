@@ -1,5 +1,5 @@
 """Measure the five BASELINE.json configs on ONE MI355X (C1..C5) and print a markdown table.
-Two frames in flight as in bench.py; ray counts from the counting kernel variant in an untimed pass."""
+Three frames in flight through trt_dist_* as in bench.py; ray counts from the counting kernel variant in an untimed pass."""
 import ctypes as C
 import os
 import sys
@@ -13,28 +13,33 @@ from terminalraytracer_amd.distributed import HipShardRenderer
 
 
 def measure(name, scene, w, h, b, frames, cameras=None):
-    r = HipShardRenderer(scene, w, h, 0, 1, 0, b, 10, depth=2)
-    r.ctx.enable_counters(True)
-    r.render(scene.camera)
-    torch.cuda.synchronize()
-    path, shadow = r.ctx.read_counters()
-    r.ctx.enable_counters(False)
+    """the calls bench.py makes: trt_dist_* with one rank, three frames in flight"""
+    d = hip.Dist(0, scene, None, 0, 1, w, h, tile_rows=8, frames_in_flight=3)
+    ctx0 = d.context(0)
+    fb = torch.zeros(h * w * 3, dtype=torch.float64, device="cuda:0")
+    ctx0.enable_counters(True)
+    ctx0.render_device(scene.camera, hip.RowSet.whole(w, h), b, 10, fb.data_ptr(), fb.numel() * 8)
+    path, shadow = ctx0.read_counters()
+    ctx0.enable_counters(False)
+    del fb
     cams = cameras or [scene.camera] * frames
     for c in cams[:3]:
-        r.render(c)
-    torch.cuda.synchronize()
+        d.render(c, b, 10)
+    d.synchronize()
     t0 = time.perf_counter()
     for c in cams:
-        r.render(c)
-    torch.cuda.synchronize()
+        d.render(c, b, 10)
+    d.synchronize()
     dt = (time.perf_counter() - t0) / len(cams)
-    r.close()
-    print(f"| {name} | {w}x{h} | {scene.num_spheres} | {b} | {dt * 1e3:.3f} | {1 / dt:.0f} | {path / dt / 1e9:.2f} | {(path + shadow) / dt / 1e9:.2f} | {path / 1e6:.1f} M |")
+    variant = ctx0.render_variant()
+    kernel = "decoupled" if variant["decoupled"] else ("plain, %d patches" % ctx0.path_patches()[1] if ctx0.path_patches()[0] else "plain")
+    d.close()
+    print(f"| {name} | {w}x{h} | {scene.num_spheres} | {b} | {dt * 1e3:.3f} | {1 / dt:.0f} | {path / dt / 1e9:.2f} | {(path + shadow) / dt / 1e9:.2f} | {path / 1e6:.1f} M | {kernel} |")
 
 
 def main():
-    print("| config | frame | spheres | bounces | ms/frame | frames/s | G path rays/s | G all rays/s | path rays/frame |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print("| config | frame | spheres | bounces | ms/frame | frames/s | G path rays/s | G all rays/s | path rays/frame | rounds |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     sky = S.synth_sky(256)
     cam = lambda w, h, t=1.0: S.orbit_camera(t, w, h)
     measure("C1 demo scene (as BASELINE words it)", S.demo_scene(sky, S.orbit_camera(1.0, 160, 48, reference_aspect=True), 3), 160, 48, 4, 200)
