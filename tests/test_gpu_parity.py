@@ -416,15 +416,18 @@ def build_rccl_stub():
 
 
 @pytest.mark.parametrize("world,width,height,tile,depth,frames,rgb8",
-                         [(2, 160, 48, 8, 3, 7, 0), (3, 67, 13, 4, 3, 8, 0), (3, 1920, 1080, 8, 3, 7, 0), (2, 1920, 1080, 8, 2, 5, 1), (3, 160, 48, 4, 3, 7, 1)],
-                         ids=["2_ranks", "3_ranks_unequal_shards", "3_ranks_1080p", "2_ranks_1080p_rgb8", "3_ranks_rgb8"])
+                         [(2, 160, 48, 8, 3, 7, 0), (3, 67, 13, 4, 3, 8, 0), (3, 1920, 1080, 8, 3, 7, 0), (2, 1920, 1080, 8, 2, 5, 1), (3, 160, 48, 4, 3, 7, 1),
+                          (2, 64, 9, 1, 1, 4, 0), (3, 40, 5, 8, 2, 5, 0), (3, 40, 5, 8, 2, 5, 1)],
+                         ids=["2_ranks", "3_ranks_unequal_shards", "3_ranks_1080p", "2_ranks_1080p_rgb8", "3_ranks_rgb8",
+                              "2_ranks_single_row_tiles_one_frame_in_flight", "3_ranks_two_without_rows", "3_ranks_two_without_rows_rgb8"])
 def test_trt_dist_with_several_ranks_on_one_gpu(ctx, tmp_path, world, width, height, tile, depth, frames, rgb8):
     """The C-ABI multi-GPU path (csrc/trt_dist.hip) EXECUTED by several ranks: `world` processes of the C host
     examples/trt_dist_demo share this box's one GPU; the eight RCCL entry points the library binds by name come from the tests'
     stand-in (tests/rccl_stub.cpp, selected by TRT_RCCL_LIB; real RCCL refuses two ranks on one device).  What runs here and
     nowhere else on a one-GPU box: the peers' ncclSend branch, the root's ncclRecv offsets for ranks >= 1, shards of unequal
-    height (13 rows in tiles of 4 over 3 ranks: 5 / 4 / 4), slots re-used while a gather is outstanding (more frames than
-    slots), messages larger than the stand-in's staging slot, and the gather of the emitter's bytes (trt_dist_render_rgb8).
+    height (13 rows in tiles of 4 over 3 ranks: 5 / 4 / 4), ranks that own NO row (5 rows in tiles of 8 over 3 ranks: nothing is
+    sent or received for them), slots re-used while a gather is outstanding (more frames than slots), messages larger than the
+    stand-in's staging slot, and the gather of the emitter's bytes (trt_dist_render_rgb8).
     Rank 0's last frame must be the frame one renderer produces for that camera."""
     import os
     import subprocess
