@@ -225,6 +225,11 @@ int trt_read_sweep_fallbacks(trt_context *ctx, unsigned long long *swept_traces)
 /* Likewise: how many times a wave ran the shadow stage (over up to 64 hits each time).  hits / (64 * passes) is the lane
  * activity of the shadow stage; the hits of a frame are shadow_rays / number of lights. */
 int trt_read_shading_passes(trt_context *ctx, unsigned long long *passes);
+/* Likewise, the exact-test loops of the three kinds of trace (path rays TRT.c:1024, directional-light shadow rays TRT.c:907,
+ * point-light shadow rays TRT.c:937): out[0..2] = wave-level iterations of each loop, out[3..5] = exact sphere tests summed over
+ * lanes (tests / (64 * iterations) = the loop's lane activity: a wave iterates as long as its busiest lane), out[6] = point-light
+ * shadow searches in which some lane's any-hit search was inconclusive and the wave ran the closest-hit search, out[7] = 0. */
+int trt_read_loop_diagnostics(trt_context *ctx, unsigned long long out[8]);
 
 /* Copy one light's table to the host (tests: the device-built table must equal the host reference builder's).
  * point_light: 0 = directional light `index`, 1 = point light `index`.  Returns the number of 64-bit words copied

@@ -74,7 +74,7 @@ int fail(int code, const char *fmt, ...)
             return fail(TRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int kCounterSlots = 32; // [path, shadow, rounds, phase-2 rounds, 24 stage stamps of the diagnostic build]
+constexpr int kCounterSlots = 40; // [path, shadow, rounds, phase-2 rounds, 24 stage stamps of the diagnostic build, swept, passes, loop diagnostics 30..36]
 constexpr int kEventRing = 256;
 constexpr double kPi = 3.14159265358979323846; // TRT.c:43
 
@@ -181,6 +181,7 @@ struct trt_context
     hipEvent_t ev_fork = nullptr;
     bool counters_enabled = false;
     unsigned long long last_trips = 0, last_phase2 = 0, last_swept = 0, last_passes = 0; // diagnostics of the counting kernel variant
+    unsigned long long last_loops[8] = {0, 0, 0, 0, 0, 0, 0, 0};                        // trt_read_loop_diagnostics
 
     hipEvent_t ev_start[kEventRing], ev_mid[kEventRing], ev_stop[kEventRing]; // launch begins | render kernel done | reduction done
     long launches = 0;
@@ -993,6 +994,14 @@ extern "C" int trt_render_variant(trt_context *ctx, int *decoupled, int *workgro
     return TRT_OK;
 }
 
+extern "C" int trt_read_loop_diagnostics(trt_context *ctx, unsigned long long out[8])
+{
+    if (!ctx || !out)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    memcpy(out, ctx->last_loops, sizeof ctx->last_loops);
+    return TRT_OK;
+}
+
 extern "C" int trt_read_shading_passes(trt_context *ctx, unsigned long long *passes)
 {
     if (!ctx || !passes)
@@ -1192,6 +1201,8 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
     ctx->last_phase2 = c[3];
     ctx->last_swept = c[28];
     ctx->last_passes = c[29];
+    for (int k = 0; k < 7; k++)
+        ctx->last_loops[k] = c[30 + k];
     if (getenv("TRT_PRINT_STAMPS"))
     { // diagnostic builds only (-DTRT_STAMP=1): per-stage wave-cycle sums
         static const char *const names[24] = {"units+primary", "unit(next_dir)", "P set-up", "P sweep", "P exact tests", "P plane",

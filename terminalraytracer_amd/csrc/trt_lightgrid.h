@@ -40,6 +40,34 @@
  *     from the light, so a hit on it is >= near farther away than the light: "lit" whether or not it is the
  *     closest hit (TRT.c:939-946 compares the nudged hit distance with the light's), and any blocker in front of
  *     the light is closer than it.  near = 0.02 + 4e-6 rg keeps that decision out of reach of the 1e-6 nudge.
+ * (4) Point light, ANY-HIT search (round 4).  apply_lighting asks trace_ray for the CLOSEST blocker and calls the point lit iff
+ *     there is none or  light_d2 < id2,  id2 = the squared distance from the origin to the blocker's hit point nudged 1e-6
+ *     back along the ray (TRT.c:871-874, :937-942).  Claim: if ANY hit j of the shadow ray (t_j > 0, TRT.c:657-659, or the
+ *     ground's t_j > 1e-5, TRT.c:685) has  d2_j <= light_d2  (d2_j as TRT.c:810-815 forms it) and  light_d2 > dark_floor,
+ *     the reference's answer is DARK.  [The closest hit c has d2_c <= d2_j <= light_d2, so it is enough to show id2_c <=
+ *     light_d2.  With D = |o - p_c| (d2_c = D^2 (1 +- 4u)) the nudged point is p_c + unit(o - p_c) 1e-6, or p_c + (o - p_c) 1e-6
+ *     when D <= 1e-4 (normalize_vector leaves short vectors alone, TRT.c:444): its distance from o is at most
+ *     max(D - 1e-6 (1 - 1e-15), D (1 - 1e-6)) + e,  e <= 2 sqrt(3) u Mg the rounding of the nudged point and of its difference
+ *     from o, Mg >= every coordinate involved.  Mg <= 2^28 gives e <= 1.1e-7.  If 1e-6 D >= 2e the distance is <= D (1 - 5e-7)
+ *     (D <= 1e-4) or <= D - 8.9e-7 (D > 1e-4; D <= rg << 1.7e9), so id2 < d2_c <= light_d2.  Otherwise D < 2e6 e and
+ *     id2 <= (D + e)^2 (1 + 4u) < 6.2e-19 Mg^2 <= dark_floor = 2^-60 Mg^2 < light_d2.]
+ *     Likewise a hit j with  id2_j > light_d2  cannot make the answer dark and may be IGNORED: if it is not the closest it plays no
+ *     part, and if it is, every other hit is at least as far and the answer is "lit" -- what the search returns when nothing
+ *     (else) is hit.  [id2_j >= ((D - delta)^2)(1 - 4u), delta = 1e-6 (1 + 1e-15) + e <= 1.2e-6, and (D - delta)^2 >= D^2 (1 -
+ *     delta) - delta.]
+ *     The kernel does not form d2_j: with q = -b - sqrt(disc) (TRT.c:657: t0 = q / (2a)) it takes
+ *         q > 2^-500  and  q^2 (1 + 2^-30) <= lo,   lo = (light_d2 - e2) 4a (1 - 2^-30)                       as proof of "dark",
+ *         q^2 >= hi,                                hi = ((light_d2 + 1.3e-6)(1 + 1.3e-6) + e2) 4a (1 + 2^-30)  as proof of "beyond",
+ *     and calls the lane UNSURE for any other q > 0 (its wave then runs the closest-hit search instead: a blocker about as far as
+ *     the light, about one wave in 1e4).  q > 2^-500 rules out an underflow of t0 (a is 1 up to 2^-40), so t0 > 0 as TRT.c:659
+ *     demands.  d2_j against q: p_j = o + t0 d and o - p_j carry <= u (|o|_inf + 3.1 |t0 d_k|) of rounding per component, so
+ *     | d2_j - t0^2 a | <= 12u t0^2 a + 2 sqrt(3) u Mg |t0| sqrt(a) <= 14u t0^2 a + 2^-52 Mg (rg + Mg)  (AM-GM; any t0), and
+ *     t0^2 a = q^2/(4a) (1 +- 2.1u):  | d2_j - q^2/(4a) | <= 2^-40 q^2/(4a) + e2/16  with  e2 = 2^-48 Mg (rg + Mg).  The ground
+ *     likewise with q := 2 a t (TRT.c:685: t > 1e-5).  Mg = |l|_inf + 2 rg bounds every coordinate of an origin the table admits
+ *     and of a hit point nearer than the light (farther hit points only enter "beyond", where their own size drowns the nudge);
+ *     if Mg > 2^28, dark_floor = +inf: lo = -1, hi = +inf, every hit is unsure (the closest-hit search, always).
+ *     tests/test_lightgrid.py drives this very classification with the oracle's shadow rays and adversarial ones: every
+ *     "dark" and every "lit" it returns must be the reference's answer.
  */
 #ifndef TRT_LIGHTGRID_H
 #define TRT_LIGHTGRID_H
@@ -68,12 +96,29 @@ typedef struct
 typedef struct
 {
     double l[3];  /* the light's position */
+    double dark_floor; /* (4): a blocker nearer than the light proves "dark" only if light_d2 > dark_floor; +inf = never */
+    double e2;         /* (4): absolute slack of d2_j against q^2 / (4a) */
     float half_g; /* g / 2 */
     float g_max;  /* g - 1 */
     float rg2;    /* admissible |o - l|^2 */
     int g;        /* cells per face side */
     int words;
 } trt_pointgrid;
+
+/* (4): the bounds a candidate's q^2 is compared with: q > 2^-500 and q^2 (1 + 2^-30) <= *lo proves "dark", q^2 >= *hi proves
+ * "beyond the light" (ignore the hit), any other q > 0 is unsure.  a = d.d of the shadow ray (1 up to 2^-40 for every ray that is
+ * looked up).  Without the guarantees of (4) (dark_floor = +inf, or NaN): *lo = -1, *hi = +inf, every hit is unsure. */
+#define TRT_SHADOW_K1 (1.0 + 0x1p-30)
+#define TRT_SHADOW_QMIN 0x1p-500
+TRT_HD void trt_point_shadow_bounds(const trt_pointgrid *G, double light_d2, double a, double *lo, double *hi)
+{
+    const double four_a = 4.0 * a;
+    const double l = (light_d2 - G->e2) * four_a * (1.0 - 0x1p-30);
+    const double h = ((light_d2 + 1.3e-6) * (1.0 + 1.3e-6) + G->e2) * four_a * (1.0 + 0x1p-30);
+    const int ok = light_d2 > G->dark_floor; /* false for NaN and for dark_floor = +inf */
+    *lo = ok ? l : -1.0;
+    *hi = ok ? h : __builtin_inf();
+}
 
 /* cell index of the shadow ray that starts at o; *far != 0: do not use the grid for this ray */
 TRT_HD int trt_dirgrid_cell(const trt_dirgrid *G, double ox, double oy, double oz, int *far)
@@ -278,6 +323,14 @@ static inline void trt_pointgrid_prepare(const double *spheres, int n, const trt
     G->rg2 = (float)(rg * rg * (1.0 - 1e-6));
     G->g = g;
     G->words = words;
+    {
+        double li = __builtin_fabs(light[0]);
+        li = __builtin_fabs(light[1]) > li ? __builtin_fabs(light[1]) : li;
+        li = __builtin_fabs(light[2]) > li ? __builtin_fabs(light[2]) : li;
+        const double Mg = li + 2.0 * rg;
+        G->dark_floor = Mg <= 0x1p28 ? 0x1p-60 * Mg * Mg : __builtin_inf(); /* also +inf for NaN */
+        G->e2 = 0x1p-48 * Mg * (rg + Mg);
+    }
     for (int i = 0; i < n; i++)
     {
         const double *s = spheres + 9 * i;

@@ -190,9 +190,13 @@ struct Hit
 // TRT.c:808-826 (strict '<': the first index wins ties).  Predicated rather than branched: a lane without a candidate
 // (`valid` false) tests sphere 0 and discards the result.  Returns true when an ANY_HIT search is answered.
 // `inside` (refraction extension only, -1 otherwise): the sphere the ray travels inside of is met at the FAR root.
-template <bool ANY_HIT, bool REFRACT = false>
+// UNIT_A (the candidates come from a table: every ray that is looked up has |a - 1| <= 2^-40): an ANY_HIT search does not form
+// t0 = q / (2a), q = -b - sqrt(disc), at all -- t0 > 0 (TRT.c:659) holds iff q > 0 unless the quotient underflows, which a
+// q > 2^-500 cannot; a q in (0, 2^-500] is divided as the reference divides it.
+template <bool ANY_HIT, bool REFRACT = false, bool UNIT_A = false>
 TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool valid, Hit &best, int inside = -1)
 {
+    static_assert(!(ANY_HIT && REFRACT), "shadow rays are the reference's");
     const double2 c01 = ((const double2 *)L.sph)[2 * i], c23 = ((const double2 *)L.sph)[2 * i + 1];
     const d3 c = d3{c01.x, c01.y, c23.x};
     const d3 oc = sub(o, c);
@@ -204,15 +208,19 @@ TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool val
     if (valid && !(disc < 0.0) && (b < 0.0 || far_root)) // b >= 0  =>  -b - sqrt(disc) <= 0  =>  t0 <= 0 or NaN: a miss (TRT.c:657-659)
     { // no further branches: selects keep `best` in place (nested ifs cost five register copies per level)
         const double root = sqrt_exact(disc);
-        const double t0 = (far_root ? -b + root : -b - root) / (2.0 * a);
-        const bool hit = t0 > 0.0;
         if (ANY_HIT)
         { // "anything in the way?" (TRT.c:908): the first hit answers it; its position is never used
+            const double q = -b - root;
+            bool hit = UNIT_A ? q > TRT_SHADOW_QMIN : q / (2.0 * a) > 0.0;
+            if (UNIT_A && q > 0.0 && !hit)
+                hit = q / (2.0 * a) > 0.0;
             best.i = hit ? i : best.i;
             done = hit;
         }
         else
         {
+            const double t0 = (far_root ? -b + root : -b - root) / (2.0 * a);
+            const bool hit = t0 > 0.0;
             const d3 p = d3{o.x + t0 * d.x, o.y + t0 * d.y, o.z + t0 * d.z};
             const double d2 = dist2(o, p);
             const bool closer = hit && d2 < best.d2;
@@ -241,7 +249,7 @@ TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool val
 
 
 template <bool ANY_HIT, bool REFRACT = false>
-TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds,
+TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds, unsigned &lane_tests,
                   const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool, int list_bits, int inside = -1
 #if TRT_STAMP
                   ,
@@ -330,13 +338,14 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         {
             phase2_rounds++;
             const bool valid = k < count;
+            lane_tests += valid;
             if (__any(valid && pooled && (k & per_mask) == 0))
                 if (valid && pooled && (k & per_mask) == 0)
                     cur = pool[at + ((unsigned)k >> per_shift)];
             const int i = valid ? (int)((unsigned)cur & entry_mask) : 0;
             cur >>= list_bits;
             k++;
-            if (exact_step<ANY_HIT, REFRACT>(L, o, d, a, i, valid, best, inside))
+            if (exact_step<ANY_HIT, REFRACT, ANY_HIT>(L, o, d, a, i, valid, best, inside))
                 count = 0;
         }
     }
@@ -387,6 +396,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
                 phase2_rounds++;
                 const int lead = __builtin_clzll(cand | 1ull);
                 const bool valid = cand != 0 && base + lead < n;
+                lane_tests += valid;
                 const int i = valid ? base + lead : 0;
                 cand &= ~(0x8000000000000000ull >> lead);
                 if (exact_step<ANY_HIT, REFRACT>(L, o, d, a, i, valid, best, inside))
@@ -418,6 +428,76 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     TRT_TRACE_STAMP(3); // plane
 #undef TRT_TRACE_STAMP
     return best;
+}
+
+// ANY-HIT search for the shadow ray of a POINT light (trt_lightgrid.h (4); TRT.c:937-942 asks for the closest blocker and whether
+// it is nearer than the light): the candidates of the ray's list cell, then the ground.  `dark`: some hit is provably nearer than
+// the light -- q > 2^-500 and q^2 (1 + 2^-30) <= lo, q = -b - sqrt(disc) the numerator of the near root (for the ground
+// q = 2 a t) -- which decides the reference's answer whichever hit is the closest; the lane stops there.  A hit provably BEYOND
+// the light (q^2 >= hi) cannot matter and is passed over.  `unsure`: the lane met a hit (q > 0) that is neither, and found no
+// proof of "dark".  Neither flag: nothing nearer than the light is hit, the point is lit.  No division, no hit point, no running
+// minimum: 3 FP64 operations and two compares per hit on top of the discriminant and its root.
+TRT_DEV void point_light_search(const LdsImage &L, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &rounds, unsigned &lane_tests,
+                                unsigned long long cell, const unsigned long long *pool, int list_bits, double lo, double hi, bool &dark, bool &unsure)
+{
+    (void)n;
+    const double a = dot(d, d);
+    const unsigned ctl = (unsigned)(cell >> 56);
+    const bool pooled = (ctl & TRT_LIST_POOLED) != 0;
+    int count = active ? (pooled ? (int)((cell >> 32) & 0xffffu) : (int)ctl) : 0;
+    const unsigned at = (unsigned)cell;
+    const unsigned entry_mask = (1u << list_bits) - 1u;
+    const int per_shift = list_bits == 8 ? 3 : 2, per_mask = (1 << per_shift) - 1;
+    unsigned long long cur = cell;
+    int k = 0;
+    dark = false, unsure = false;
+    while (__any(k < count))
+    {
+        rounds++;
+        const bool valid = k < count;
+        lane_tests += valid;
+        if (__any(valid && pooled && (k & per_mask) == 0))
+            if (valid && pooled && (k & per_mask) == 0)
+                cur = pool[at + ((unsigned)k >> per_shift)];
+        const int i = valid ? (int)((unsigned)cur & entry_mask) : 0;
+        cur >>= list_bits;
+        k++;
+        const double2 c01 = ((const double2 *)L.sph)[2 * i], c23 = ((const double2 *)L.sph)[2 * i + 1];
+        const d3 oc = sub(o, d3{c01.x, c01.y, c23.x});
+        const double b = 2.0 * dot(oc, d);
+        const double cc = dot(oc, oc) - c23.y;
+        const double disc = b * b - 4.0 * a * cc;
+        if (valid && !(disc < 0.0) && b < 0.0) // b >= 0: t0 <= 0 or NaN, a miss (TRT.c:657-659)
+        {
+            const double q = -b - sqrt_exact(disc), qq = q * q;
+            const bool blocks = q > TRT_SHADOW_QMIN && qq * TRT_SHADOW_K1 <= lo;
+            unsure = unsure || (q > 0.0 && !blocks && !(qq >= hi));
+            dark = dark || blocks;
+            count = blocks ? 0 : count;
+        }
+    }
+    // the ground (TRT.c:677-695) for the lanes that are not dark yet
+    if (__any(active && !dark))
+    {
+        const double denom = dot(d, gn);
+        if (active && !dark && __builtin_fabs(denom) > 0.00001)
+        {
+            const double num = dot(sub(gp, o), gn);
+            // opposite signs: t <= 0, a miss (as in hit_plane: a wave whose rays all head away from the plane skips the division)
+            if ((long long)(__builtin_bit_cast(unsigned long long, num) ^ __builtin_bit_cast(unsigned long long, denom)) >= 0)
+            {
+                const double t = num / denom;
+                if (t > 0.00001)
+                {
+                    const double qq = (t * t) * (4.0 * a) * a; // q = 2 a t
+                    const bool blocks = qq * TRT_SHADOW_K1 <= lo;
+                    dark = blocks;
+                    unsure = unsure || (!blocks && !(qq >= hi));
+                }
+            }
+        }
+    }
+    unsure = unsure && !dark;
 }
 
 // The list cell of a PATH ray (trt_raygrid.h), ONE FAMILY PER SPHERE (GridView::patch_m == 0).  `fam`: the family the ray is
@@ -523,7 +603,10 @@ TRT_DEV unsigned lanes_below(unsigned long long mask)
 // Per-lane counters of the counting kernel variant and the stamps of the diagnostic build, handed through the stages.
 struct Tally
 {
-    unsigned path = 0, shadow = 0, rounds = 0, phase2 = 0, swept = 0, passes = 0;
+    unsigned path = 0, shadow = 0, rounds = 0, swept = 0, passes = 0;
+    unsigned iters[3] = {0, 0, 0}; // wave-level iterations of the exact-test loops: path rays, directional-light shadow rays, point-light ones
+    unsigned tests[3] = {0, 0, 0}; // exact tests of THIS lane in those loops (tests / (64 iters) = the loops' lane activity)
+    unsigned full = 0;             // point-light shadow searches that fell back from the any-hit form to the closest-hit one
 #if TRT_STAMP
     unsigned long long stamp_sum[24] = {0}, stamp_prev = 0;
 #endif
@@ -572,10 +655,10 @@ TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridVi
         tally.swept++;
     PathHit r;
 #if TRT_STAMP
-    r.ph = trace<false, REFRACT>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside, stamp_sum,
+    r.ph = trace<false, REFRACT>(L, cull, n, o, d, alive, gp, gn, tally.iters[0], tally.tests[0], nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside, stamp_sum,
                                  &stamp_prev, 2);
 #else
-    r.ph = trace<false, REFRACT>(L, cull, n, o, d, alive, gp, gn, tally.phase2, nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside);
+    r.ph = trace<false, REFRACT>(L, cull, n, o, d, alive, gp, gn, tally.iters[0], tally.tests[0], nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside);
 #endif
     r.hit = alive && r.ph.i >= 0;
     r.sky = alive && r.ph.i < 0;
@@ -638,10 +721,10 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
                 tally.swept++;
             TRT_STAMP_AT(8); // look-up
 #if TRT_STAMP
-            const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, L.cull_dir + li * cull.padded, use_list, cell, grids.pool,
+            const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[1], tally.tests[1], L.cull_dir + li * cull.padded, use_list, cell, grids.pool,
                                        grids.list_bits, -1, stamp_sum, &stamp_prev, 9);
 #else
-            const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, L.cull_dir + li * cull.padded, use_list, cell, grids.pool, grids.list_bits);
+            const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[1], tally.tests[1], L.cull_dir + li * cull.padded, use_list, cell, grids.pool, grids.list_bits);
 #endif
             is_lit = sh.i < 0;
             factor = min1(dot(normal, sd));
@@ -670,27 +753,48 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
             if (COUNT && !use_list)
                 tally.swept++;
             TRT_STAMP_AT(14); // unit(to_light), strength, look-up
-#if TRT_STAMP
-            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool, grids.list_bits, -1, stamp_sum, &stamp_prev, 15);
-#else
-            const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.phase2, nullptr, use_list, cell, grids.pool, grids.list_bits);
-#endif
-            is_lit = sh.i < 0;
-            // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the
-            // blocker point NUDGED 1e-6 back along the ray (TRT.c:871-874, :939-942): (D - 1e-6)^2 up to ~1e-14 relative
-            // rounding, where D^2 = sh.d2 (1 +- 4u).  From D <= (D^2+1)/2:
-            //     (D-1e-6)^2 (1-1e-14)  >=  sh.d2 (1 - 1.01e-6) - 1.01e-6      and, for D >= 1e-5,   (D-1e-6)^2 (1+1e-14) < sh.d2.
-            // Outside that band the answer is certain without normalising anything; inside it (about one ray in 1e5)
-            // the exact nudged point is formed as the reference does.
-            const bool surely_lit = light_d2 < sh.d2 * (1.0 - 1.01e-6) - 1.01e-6;
-            const bool surely_dark = sh.d2 > 1e-10 && light_d2 >= sh.d2;
-            if (sh.i >= 0)
-                is_lit = surely_lit;
-            if (__any(lit_lanes && sh.i >= 0 && !surely_lit && !surely_dark))
+            // ANY-HIT search (trt_lightgrid.h (4)): a candidate that is provably hit nearer than the light proves "dark", whichever
+            // hit is the closest; no hit at all is "lit"; anything else (a blocker about as far as the light) leaves the lane
+            // unsure and sends its wave through the closest-hit search of TRT.c:937-942 below.
+            bool full = !use_list;
+            is_lit = true;
+            if (use_list)
             {
-                const d3 to_blocker = sub(add(sh.p, scale(unit(sub(o, sh.p)), 0.000001)), o);
-                if (sh.i >= 0 && !surely_lit && !surely_dark)
-                    is_lit = light_d2 < dot(to_blocker, to_blocker);
+                const trt_pointgrid *G = L.pointgrid + (li - nd);
+                double lo, hi;
+                trt_point_shadow_bounds(G, light_d2, dot(sd, sd), &lo, &hi);
+                bool dark, unsure;
+                point_light_search(L, n, o, sd, lit_lanes, gp, gn, tally.iters[2], tally.tests[2], cell, grids.pool, grids.list_bits, lo, hi, dark, unsure);
+                is_lit = !dark;
+                full = __any(lit_lanes && unsure);
+                TRT_STAMP_AT(17); // any-hit search
+            }
+            if (full)
+            {
+                if (COUNT)
+                    tally.full++;
+#if TRT_STAMP
+                const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[2], tally.tests[2], nullptr, use_list, cell, grids.pool, grids.list_bits, -1, stamp_sum, &stamp_prev, 15);
+#else
+                const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[2], tally.tests[2], nullptr, use_list, cell, grids.pool, grids.list_bits);
+#endif
+                is_lit = sh.i < 0;
+                // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the
+                // blocker point NUDGED 1e-6 back along the ray (TRT.c:871-874, :939-942): (D - 1e-6)^2 up to ~1e-14 relative
+                // rounding, where D^2 = sh.d2 (1 +- 4u).  From D <= (D^2+1)/2:
+                //     (D-1e-6)^2 (1-1e-14)  >=  sh.d2 (1 - 1.01e-6) - 1.01e-6      and, for D >= 1e-5,   (D-1e-6)^2 (1+1e-14) < sh.d2.
+                // Outside that band the answer is certain without normalising anything; inside it the exact nudged point is
+                // formed as the reference does.
+                const bool surely_lit = light_d2 < sh.d2 * (1.0 - 1.01e-6) - 1.01e-6;
+                const bool surely_dark = sh.d2 > 1e-10 && light_d2 >= sh.d2;
+                if (sh.i >= 0)
+                    is_lit = surely_lit;
+                if (__any(lit_lanes && sh.i >= 0 && !surely_lit && !surely_dark))
+                {
+                    const d3 to_blocker = sub(add(sh.p, scale(unit(sub(o, sh.p)), 0.000001)), o);
+                    if (sh.i >= 0 && !surely_lit && !surely_dark)
+                        is_lit = light_d2 < dot(to_blocker, to_blocker);
+                }
             }
             factor = strength * min1(dot(normal, sd));
             TRT_STAMP_AT(19); // point shadow tail
@@ -1179,12 +1283,17 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
     {
         atomicAdd(&f.counters[0], (unsigned long long)tally.path);
         atomicAdd(&f.counters[1], (unsigned long long)tally.shadow);
+        for (int k = 0; k < 3; k++)
+            atomicAdd(&f.counters[33 + k], (unsigned long long)tally.tests[k]); // exact tests per lane: tests / (64 iterations) = lane activity
         if (lane == 0)
         {
             atomicAdd(&f.counters[2], (unsigned long long)tally.rounds);
-            atomicAdd(&f.counters[3], (unsigned long long)tally.phase2);
+            atomicAdd(&f.counters[3], (unsigned long long)tally.iters[0] + tally.iters[1] + tally.iters[2]);
             atomicAdd(&f.counters[28], (unsigned long long)tally.swept); // traces in which the wave fell back to the sweep
             atomicAdd(&f.counters[29], (unsigned long long)tally.passes); // times the wave ran the shadow stage
+            for (int k = 0; k < 3; k++)
+                atomicAdd(&f.counters[30 + k], (unsigned long long)tally.iters[k]); // wave-level iterations of the three exact-test loops
+            atomicAdd(&f.counters[36], (unsigned long long)tally.full);            // point-light searches that fell back to the closest hit
 #if TRT_STAMP
             for (int i = 0; i < 24; i++)
                 atomicAdd(&f.counters[4 + i], stamp_sum[i]);

@@ -81,6 +81,7 @@ SYMBOLS = {
     "trt_read_path_tables": (C.c_long, [_VP, C.POINTER(L.Camera), _VP, C.c_size_t, _VP, C.c_size_t, C.POINTER(C.c_long)]),
     "trt_read_sweep_fallbacks": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
     "trt_read_shading_passes": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
+    "trt_read_loop_diagnostics": (_I, [_VP, C.POINTER(C.c_ulonglong)]),
     "trt_set_refraction": (_I, [_VP, _VP, _I]),
     "trt_reserve_cus": (_I, [_VP, _I]),
     "trt_get_stream": (_I, [_VP, C.POINTER(C.c_void_p)]),
@@ -336,7 +337,13 @@ class Context:
         _check(lib().trt_read_diagnostics(self._h, C.byref(t), C.byref(p)))
         v = C.c_ulonglong()
         _check(lib().trt_read_shading_passes(self._h, C.byref(v)))
-        return {"wave_loop_trips": t.value, "phase2_rounds": p.value, "swept_traces": self.read_sweep_fallbacks(), "shading_passes": v.value}
+        loops = (C.c_ulonglong * 8)()
+        _check(lib().trt_read_loop_diagnostics(self._h, loops))
+        kinds = ("path", "directional", "point")
+        return {"wave_loop_trips": t.value, "phase2_rounds": p.value, "swept_traces": self.read_sweep_fallbacks(), "shading_passes": v.value,
+                "exact_loop_iterations": {k: int(loops[i]) for i, k in enumerate(kinds)},
+                "exact_loop_lane_activity": {k: round(loops[3 + i] / max(1, 64 * loops[i]), 4) for i, k in enumerate(kinds)},
+                "point_light_closest_hit_fallbacks": int(loops[6])}
 
     def kernel_info(self):
         v = [_I() for _ in range(5)]

@@ -24,6 +24,11 @@ class Stats(C.Structure):
                 ("cand_hist", C.c_ulonglong * 17), ("first_violation", C.c_double * 8)]
 
 
+class AnyHitStats(C.Structure):
+    _fields_ = [(k, C.c_ulonglong) for k in ("rays", "far", "dark", "lit", "unsure", "wrong_dark", "wrong_lit", "tests", "tests_closest")] + \
+               [("first_wrong", C.c_double * 6)]
+
+
 @pytest.fixture(scope="module")
 def checker():
     build = os.path.join(T.ROOT, "tests", "_build")
@@ -39,7 +44,20 @@ def checker():
     lib.dirgrid_check.restype = None
     lib.pointgrid_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Stats)]
     lib.pointgrid_check.restype = None
+    lib.pointgrid_anyhit_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(AnyHitStats)]
+    lib.pointgrid_anyhit_check.restype = None
     return lib
+
+
+def run_anyhit(checker, spheres, ground, light, rays, g):
+    spheres = np.ascontiguousarray(spheres, dtype=np.float64).reshape(-1, 9)
+    rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+    light = np.ascontiguousarray(light, dtype=np.float64)
+    ground = None if ground is None else np.ascontiguousarray(ground, dtype=np.float64)
+    st = AnyHitStats()
+    checker.pointgrid_anyhit_check(spheres.ctypes.data, spheres.shape[0], None if ground is None else ground.ctypes.data, light.ctypes.data,
+                                   rays.ctypes.data, rays.shape[0], g, C.byref(st))
+    return st
 
 
 def run_dir(checker, spheres, rays, g):
@@ -173,3 +191,88 @@ def test_point_masks_are_conservative_on_adversarial_origins(checker):
             assert st.decision_mismatches == 0, (trial, g)
         hits += st.exact_hits
     assert hits > 20000
+
+
+# ---- the any-hit search of a point light's shadow rays (trt_lightgrid.h (4)) ----
+
+@pytest.mark.parametrize("name,make,w,h,b", FRAMES, ids=[f[0] for f in FRAMES])
+def test_any_hit_search_decides_as_the_reference_on_real_frames(checker, name, make, w, h, b):
+    """Every "dark" and every "lit" of the division-free any-hit classification the kernel runs for point lights must be the answer
+    of the reference's closest-hit decision (all spheres and the ground, nudged blocker point, TRT.c:937-942); "unsure" -- which
+    sends the wave through the closest-hit search -- must be rare."""
+    scene = make()
+    rays, kinds = traced_rays(scene, w, h, b, 10)
+    point = rays[kinds == 2]
+    for g in (16, 64):
+        st = run_anyhit(checker, scene.spheres, scene.ground, scene.point_lights[0, :3], point, g)
+        print(f"\n{name} g {g}: rays {st.rays} far {st.far} dark {st.dark} lit {st.lit} unsure {st.unsure} "
+              f"tests any-hit {st.tests / max(1, st.rays - st.far):.3f} closest-hit {st.tests_closest / max(1, st.rays - st.far):.3f}")
+        assert st.wrong_dark == 0 and st.wrong_lit == 0, list(st.first_wrong)
+        assert st.dark > 1000 and st.lit > 1000 and st.far < 0.02 * st.rays
+        assert st.unsure <= 1e-3 * st.rays
+
+
+def test_any_hit_search_on_adversarial_origins(checker):
+    """Blockers at (almost) exactly the light's distance, origins a hair off a sphere (the ray re-enters it after 1e-9 ... 1e-4),
+    lights inside / next to spheres, scenes far from the origin (coordinates up to 1e9: the dark_floor / e2 bounds scale with them,
+    and beyond 2^28 every hit must come back unsure), grounds that block: never a wrong "dark" or "lit"."""
+    rng = np.random.default_rng(31)
+    decided = unsure = 0
+    for trial in range(16):
+        n_s = int(rng.integers(1, 120))
+        sph, scale, shift = _random_scene(rng, n_s)
+        if trial % 4 == 3:
+            shift = shift + rng.normal(size=3) * 10.0 ** rng.uniform(5, 9)
+            sph[:, :3] += shift
+        light = sph[:, :3].mean(axis=0) + rng.normal(size=3) * scale * 10.0 ** rng.uniform(-1, 1)
+        if trial % 5 == 1:
+            light = sph[0, :3] + _unit(rng.normal(size=3)) * sph[0, 3] * 0.5
+        ground = np.zeros(16)
+        ground[0:3] = sph[:, :3].mean(axis=0) - [0, scale, 0]
+        ground[3:6] = _unit(np.array([0.0, 1.0, 0.0]) + rng.normal(size=3) * 0.2) * 10.0 ** rng.uniform(-1, 1)
+        m = 20000
+        k = rng.integers(0, n_s, m)
+        c, r = sph[k, :3], np.abs(sph[k, 3])
+        # (a) origins on the far side of sphere k from the light, at offsets that put the NEAR hit at the light's distance +- tiny
+        u = _unit(rng.normal(size=(m, 3)))
+        o_a = light + u * np.linalg.norm(c - light, axis=1, keepdims=True) * rng.uniform(1.0, 3.0, (m, 1))
+        # (b) origins a hair outside sphere k, the light behind the surface: the ray re-enters its own sphere at once
+        nrm = _unit(rng.normal(size=(m, 3)))
+        o_b = c + nrm * (r * (1 + 10.0 ** rng.uniform(-12, -3, m)))[:, None]
+        # (c) origins such that the blocker's near hit is at the light's distance times 1 +- 1e-16 .. 1e-3
+        tow = _unit(c - light)
+        o_c = light + tow * (np.linalg.norm(c - light, axis=1) - r)[:, None] * (1 + rng.choice(OFFSETS, m))[:, None] * rng.choice([1.0, 2.0], (m, 1))
+        # (d) ground points (shadow rays that graze or hit the ground)
+        gn = _unit(ground[3:6])
+        t1 = np.cross(gn, [1.0, 0.3, 0.2])
+        t1 /= np.linalg.norm(t1)
+        t2 = np.cross(gn, t1)
+        o_d = ground[0:3] + (rng.normal(size=(m, 1)) * t1 + rng.normal(size=(m, 1)) * t2) * scale * 3 + gn * (10.0 ** rng.uniform(-9, 0, (m, 1))) * scale * rng.choice([-1.0, 1.0], (m, 1))
+        o = np.concatenate([o_a, o_b, o_c, o_d])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            d = _unit(light - o)
+        rays = np.concatenate([o, d], axis=1)
+        for g in (8, 64):
+            st = run_anyhit(checker, sph, ground, light, rays, g)
+            assert st.wrong_dark == 0 and st.wrong_lit == 0, (trial, g, list(st.first_wrong))
+        decided += st.dark + st.lit
+        unsure += st.unsure
+        if np.abs(light).max() + 2 * 256 * 3 * scale > 2.0 ** 28 * 4:
+            pass
+    print(f"\nany-hit on adversarial origins: decided {decided}, unsure {unsure}")
+    assert decided > 200000
+
+
+def test_any_hit_search_is_switched_off_for_astronomic_coordinates(checker):
+    """Mg > 2^28: the bounds of trt_lightgrid.h (4) do not hold, so no hit may be taken as proof of "dark" (every hit is unsure)."""
+    rng = np.random.default_rng(32)
+    sph = np.zeros((20, 9))
+    sph[:, :3] = rng.normal(size=(20, 3)) + 3e9
+    sph[:, 3] = 0.3
+    light = sph[:, :3].mean(axis=0) + [0.0, 4.0, 0.0]
+    o = sph[rng.integers(0, 20, 5000), :3] - [0.0, 2.0, 0.0] + rng.normal(size=(5000, 3)) * 0.2
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d = _unit(light - o)
+    st = run_anyhit(checker, sph, None, light, np.concatenate([o, d], axis=1), 32)
+    print(f"\nastronomic: rays {st.rays} far {st.far} dark {st.dark} lit {st.lit} unsure {st.unsure}")
+    assert st.dark == 0 and st.wrong_lit == 0
