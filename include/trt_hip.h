@@ -158,6 +158,11 @@ int trt_set_kernel(trt_context *ctx, int which);
  * whenever the spheres or the lights change.  0, 0 turns the tables off (every shadow ray sweeps); results are
  * bit-identical either way.  Defaults: 128 and 64; environment TRT_LIGHTGRID="d,p" overrides the defaults. */
 int trt_set_light_grids(trt_context *ctx, int directional_cells, int point_cells);
+/* The tables' third coordinate (csrc/trt_lightgrid.h (5)): `directional_slabs` slabs of depth along a directional light's
+ * direction, `point_shells` shells of distance from a point light (1..64 each); a cell then lists only the spheres that can lie
+ * between an origin of its slab and the light -- about half the column in a dense scene.  1, 1: the two-parameter tables of
+ * rounds 1-3.  Defaults 16 and 16; TRT_LIGHTGRID="d,p,slabs,shells" sets all four.  Frames are bit-identical for every value. */
+int trt_set_light_slabs(trt_context *ctx, int directional_slabs, int point_shells);
 
 /* Candidate tables of the PATH rays (csrc/trt_raygrid.h): path rays come in families that pass (nearly) through one point --
  * the eye, its mirror image in the ground, a sphere, a sphere's mirror image -- and each family has a cube map of
@@ -233,7 +238,7 @@ int trt_read_loop_diagnostics(trt_context *ctx, unsigned long long out[8]);
 
 /* Copy one light's table to the host (tests: the device-built table must equal the host reference builder's).
  * point_light: 0 = directional light `index`, 1 = point light `index`.  Returns the number of 64-bit words copied
- * (cells * ceil(N/64)), 0 when the tables are off, or a negative TRT_ERR_*. */
+ * (cells * ceil(N/64); cells = slabs * g^2 resp. shells * 6 g^2), 0 when the tables are off, or a negative TRT_ERR_*. */
 long trt_read_light_grid(trt_context *ctx, int point_light, int index, unsigned long long *masks, size_t capacity_words);
 
 /* Resource usage of the render kernel the next frame runs (hipFuncGetAttributes / occupancy query; max_blocks_per_cu counts

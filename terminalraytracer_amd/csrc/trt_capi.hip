@@ -23,6 +23,13 @@
 #ifndef TRT_POINTGRID_CELLS
 #define TRT_POINTGRID_CELLS 64
 #endif
+// ... and their third coordinate (trt_lightgrid.h (5)): slabs of depth along a directional light, shells of distance from a point light
+#ifndef TRT_DIRGRID_SLABS
+#define TRT_DIRGRID_SLABS 16
+#endif
+#ifndef TRT_POINTGRID_SHELLS
+#define TRT_POINTGRID_SHELLS 16
+#endif
 
 // candidate tables of the path rays' families (trt_raygrid.h): cells per side of a cube-map face for the two families of
 // the eye / for the 2N families of the spheres
@@ -136,6 +143,7 @@ struct trt_context
     DeviceBuffer<trt_pointgrid_cone> d_cones; // per point light and sphere
     trt::GridView grids{};
     int dirgrid_cells = TRT_DIRGRID_CELLS, pointgrid_cells = TRT_POINTGRID_CELLS; // per side; 0 = no tables (sweep only)
+    int dirgrid_slabs = TRT_DIRGRID_SLABS, pointgrid_shells = TRT_POINTGRID_SHELLS; // depth coordinate of the light tables (>= 1)
     // the tables as LIST CELLS (trt_raygrid.h), which is what the kernel reads: one 64-bit word per cell, long lists in d_pool
     DeviceBuffer<unsigned long long> d_dir_lists, d_point_lists, d_path_lists, d_pool;
     DeviceBuffer<unsigned int> d_pool_used;    // [0] words taken by the scene's tables, [16] by the eye's (a cache line apart)
@@ -151,7 +159,7 @@ struct trt_context
     double eye_built[3] = {0.0, 0.0, 0.0}, ground_built[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     bool eye_tables_valid = false;
     std::vector<double> h_spheres, h_dir, h_point; // what the tables on the device were built from
-    int grids_built_for[2] = {-1, -1};
+    int grids_built_for[4] = {-1, -1, -1, -1};
     DeviceBuffer<uint32_t> d_sky;
     DeviceBuffer<double> d_ior; // refraction extension: per sphere, > 0 = index of refraction
     DeviceBuffer<unsigned char> d_rgb8; // trt_render_host_rgb8: the quantised frame before it crosses PCIe
@@ -288,33 +296,33 @@ int upload_skybox(trt_context *ctx, const Skybox *sky)
 
 // Marking kernels of the light-space tables: one thread per cell, every sphere tested with the predicates of
 // trt_lightgrid.h (+ - * / sqrt only: the host reference builders in the tests produce the same bits).
-__global__ void build_dirgrid_kernel(const trt_dirgrid_disc *discs, int n, int g, int words, unsigned long long *masks)
+__global__ void build_dirgrid_kernel(const trt_dirgrid_disc *discs, int n, int g, int slabs, int words, unsigned long long *masks)
 {
     const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= (long)g * g)
+    if (cell >= (long)slabs * g * g)
         return;
-    const int c = (int)(cell % g), j = (int)(cell / g);
+    const int c = (int)(cell % g), j = (int)((cell / g) % g), slab = (int)(cell / ((long)g * g));
     for (int w = 0; w < words; w++)
     {
         unsigned long long m = 0;
         for (int b = 0; b < 64 && w * 64 + b < n; b++)
-            if (trt_dirgrid_reaches(discs + w * 64 + b, c, j))
+            if (trt_dirgrid_in_slab(discs + w * 64 + b, slab) && trt_dirgrid_reaches(discs + w * 64 + b, c, j))
                 m |= 0x8000000000000000ull >> b;
         masks[cell * words + w] = m;
     }
 }
 
-__global__ void build_pointgrid_kernel(const trt_pointgrid_cone *cones, int n, int g, int words, unsigned long long *masks)
+__global__ void build_pointgrid_kernel(const trt_pointgrid_cone *cones, int n, int g, int shells, int words, unsigned long long *masks)
 {
     const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= 6L * g * g)
+    if (cell >= 6L * shells * g * g)
         return;
-    const int face = (int)(cell / ((long)g * g)), j = (int)((cell / g) % g), c = (int)(cell % g);
+    const int shell = (int)(cell / (6L * g * g)), face = (int)((cell / ((long)g * g)) % 6), j = (int)((cell / g) % g), c = (int)(cell % g);
     for (int w = 0; w < words; w++)
     {
         unsigned long long m = 0;
         for (int b = 0; b < 64 && w * 64 + b < n; b++)
-            if (trt_pointgrid_reaches(cones + w * 64 + b, face, c, j, g))
+            if (trt_pointgrid_in_shell(cones + w * 64 + b, shell, shells) && trt_pointgrid_reaches(cones + w * 64 + b, face, c, j, g))
                 m |= 0x8000000000000000ull >> b;
         masks[cell * words + w] = m;
     }
@@ -373,17 +381,19 @@ __global__ __launch_bounds__(256) void build_family_lists_kernel(const double *s
 int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
 {
     const int n = (int)(ctx->h_spheres.size() / 9), nd = (int)(ctx->h_dir.size() / 6), np = (int)(ctx->h_point.size() / 7);
-    const int gd = ctx->dirgrid_cells, gp = ctx->pointgrid_cells;
+    const int gd = ctx->dirgrid_cells, gp = ctx->pointgrid_cells, sd = std::max(ctx->dirgrid_slabs, 1), sp = std::max(ctx->pointgrid_shells, 1);
     trt::GridView &g = ctx->grids;
     g.enabled = 0;
     ctx->grids_built_for[0] = gd;
     ctx->grids_built_for[1] = gp;
+    ctx->grids_built_for[2] = ctx->dirgrid_slabs;
+    ctx->grids_built_for[3] = ctx->pointgrid_shells;
     if (gd < 8 || gp < 2 || nd + np == 0 || n > TRT_LIST_MAX_SPHERES_WIDE)
         return TRT_OK; // enabled = 0: the kernel sweeps
     const int bits = n > TRT_LIST_MAX_SPHERES ? 16 : 8; // entry width of the list cells
     g.list_bits = bits;
     const size_t words = (size_t)std::max((n + 63) / 64, 1), slots = (size_t)std::max(n, 1);
-    const size_t dir_stride = (size_t)gd * gd * words, point_stride = 6 * (size_t)gp * gp * words;
+    const size_t dir_stride = (size_t)sd * gd * gd * words, point_stride = 6 * (size_t)sp * gp * gp * words;
     std::vector<trt_dirgrid> dg(nd);
     std::vector<trt_pointgrid> pg(np);
     std::vector<trt_dirgrid_disc> discs(slots * nd);
@@ -395,10 +405,10 @@ int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
         const double len2 = to_light[0] * to_light[0] + to_light[1] * to_light[1] + to_light[2] * to_light[2];
         if (!(len2 > 0.0) || !(len2 < 1e300))
             return TRT_OK; // a light without a direction: leave the tables off
-        trt_dirgrid_prepare(ctx->h_spheres.data(), n, &cs, to_light, gd, &dg[i], discs.data() + slots * i);
+        trt_dirgrid_prepare(ctx->h_spheres.data(), n, &cs, to_light, gd, sd, &dg[i], discs.data() + slots * i);
     }
     for (int i = 0; i < np; i++)
-        trt_pointgrid_prepare(ctx->h_spheres.data(), n, &cs, ctx->h_point.data() + 7 * i, gp, &pg[i], cones.data() + slots * i);
+        trt_pointgrid_prepare(ctx->h_spheres.data(), n, &cs, ctx->h_point.data() + 7 * i, gp, sp, &pg[i], cones.data() + slots * i);
     HIP_TRY(ctx->d_dir_masks.reserve(dir_stride * nd));
     HIP_TRY(ctx->d_point_masks.reserve(point_stride * np));
     HIP_TRY(ctx->d_dirgrids.reserve(nd));
@@ -417,13 +427,13 @@ int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
     }
     const int block = 256;
     for (int i = 0; i < nd; i++)
-        hipLaunchKernelGGL(build_dirgrid_kernel, dim3((unsigned)(((size_t)gd * gd + block - 1) / block)), dim3(block), 0, ctx->stream,
-                           ctx->d_discs.ptr + slots * i, n, gd, (int)words, ctx->d_dir_masks.ptr + dir_stride * i);
+        hipLaunchKernelGGL(build_dirgrid_kernel, dim3((unsigned)(((size_t)sd * gd * gd + block - 1) / block)), dim3(block), 0, ctx->stream,
+                           ctx->d_discs.ptr + slots * i, n, gd, sd, (int)words, ctx->d_dir_masks.ptr + dir_stride * i);
     for (int i = 0; i < np; i++)
-        hipLaunchKernelGGL(build_pointgrid_kernel, dim3((unsigned)((6 * (size_t)gp * gp + block - 1) / block)), dim3(block), 0, ctx->stream,
-                           ctx->d_cones.ptr + slots * i, n, gp, (int)words, ctx->d_point_masks.ptr + point_stride * i);
+        hipLaunchKernelGGL(build_pointgrid_kernel, dim3((unsigned)((6 * (size_t)sp * gp * gp + block - 1) / block)), dim3(block), 0, ctx->stream,
+                           ctx->d_cones.ptr + slots * i, n, gp, sp, (int)words, ctx->d_point_masks.ptr + point_stride * i);
     // the kernel reads list cells: pack every table (the mask words stay for trt_read_light_grid)
-    const size_t dir_cells = (size_t)gd * gd, point_cells = 6 * (size_t)gp * gp;
+    const size_t dir_cells = (size_t)sd * gd * gd, point_cells = 6 * (size_t)sp * gp * gp;
     HIP_TRY(ctx->d_dir_lists.reserve(dir_cells * nd));
     HIP_TRY(ctx->d_point_lists.reserve(point_cells * np));
     if (nd)
@@ -524,16 +534,17 @@ int build_tables(trt_context *ctx, const trt_cull_scene &cs, const double *groun
 {
     const size_t n = ctx->h_spheres.size() / 9, nd = ctx->h_dir.size() / 6, np = ctx->h_point.size() / 7;
     const size_t gd = (size_t)ctx->dirgrid_cells, gp = (size_t)ctx->pointgrid_cells, ge = (size_t)ctx->path_g_eye, gs = (size_t)ctx->path_g_sph;
+    const size_t sd = (size_t)std::max(ctx->dirgrid_slabs, 1), sp = (size_t)std::max(ctx->pointgrid_shells, 1);
     // one pool word per cell; the many small tables of sub-families (their lists are short: that is what they are for) get
     // half a word per cell -- a list that finds no room leaves its cell TRT_LIST_NONE and its rays sweep
     const int m = patches_for(ctx, (int)n);
     const size_t sphere_cells = 2 * n * (m ? 6 * (size_t)m * m : 1) * 6 * gs * gs;
-    ctx->pool_scene_words = std::max<size_t>(1024, nd * gd * gd + np * 6 * gp * gp + (m ? sphere_cells / 2 : sphere_cells));
+    ctx->pool_scene_words = std::max<size_t>(1024, nd * sd * gd * gd + np * 6 * sp * gp * gp + (m ? sphere_cells / 2 : sphere_cells));
     ctx->pool_eye_words = std::max<size_t>(1024, 2 * 6 * ge * ge);
     if (ctx->pool_scene_words + ctx->pool_eye_words >= 0xffffffffull)
         return fail(TRT_ERR_CAPACITY, "candidate tables too large");
     if (n > TRT_LIST_MAX_SPHERES) // no sphere families; 16-bit entries: long lists take twice the words
-        ctx->pool_scene_words = std::max<size_t>(1024, 2 * (nd * gd * gd + np * 6 * gp * gp));
+        ctx->pool_scene_words = std::max<size_t>(1024, 2 * (nd * sd * gd * gd + np * 6 * sp * gp * gp));
     ctx->grids = trt::GridView{};
     ctx->grids.list_bits = 8;
     HIP_TRY(ctx->d_pool.reserve(ctx->pool_scene_words + ctx->pool_eye_words));
@@ -633,6 +644,7 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
                       (!nd || !memcmp(ctx->h_dir.data(), hd, (size_t)nd * sizeof(DirectionalLight))) &&
                       (!np || !memcmp(ctx->h_point.data(), hp, (size_t)np * sizeof(PointLight))) &&
                       ctx->grids_built_for[0] == ctx->dirgrid_cells && ctx->grids_built_for[1] == ctx->pointgrid_cells &&
+                      ctx->grids_built_for[2] == ctx->dirgrid_slabs && ctx->grids_built_for[3] == ctx->pointgrid_shells &&
                       ctx->path_built_for[0] == ctx->path_g_eye && ctx->path_built_for[1] == ctx->path_g_sph &&
                       ctx->path_built_for[2] == ctx->path_min_spheres && ctx->path_built_for[3] == ctx->path_patches &&
                       !memcmp(ctx->ground_built, &scene->ground, sizeof ctx->ground_built);
@@ -644,7 +656,7 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
         const int rc = build_tables(ctx, cs, (const double *)&scene->ground);
         if (rc)
         {
-            ctx->grids_built_for[0] = ctx->grids_built_for[1] = -1;
+            ctx->grids_built_for[0] = ctx->grids_built_for[1] = ctx->grids_built_for[2] = ctx->grids_built_for[3] = -1;
             return rc;
         }
     }
@@ -765,9 +777,9 @@ static int init_context(trt_context *ctx)
     ctx->lds_limit = (int)prop.sharedMemPerBlock;
     if (const char *e = getenv("TRT_LIGHTGRID"))
     {
-        int gd = 0, gp = 0;
-        if (sscanf(e, "%d,%d", &gd, &gp) == 2 && gd >= 0 && gp >= 0 && gd <= 2048 && gp <= 1024)
-            ctx->dirgrid_cells = gd, ctx->pointgrid_cells = gp;
+        int gd = 0, gp = 0, sd = TRT_DIRGRID_SLABS, sp = TRT_POINTGRID_SHELLS;
+        if (sscanf(e, "%d,%d,%d,%d", &gd, &gp, &sd, &sp) >= 2 && gd >= 0 && gp >= 0 && gd <= 2048 && gp <= 1024 && sd >= 1 && sp >= 1 && sd <= 64 && sp <= 64)
+            ctx->dirgrid_cells = gd, ctx->pointgrid_cells = gp, ctx->dirgrid_slabs = sd, ctx->pointgrid_shells = sp;
     }
     if (const char *e = getenv("TRT_PATHGRID"))
     {
@@ -1042,6 +1054,15 @@ extern "C" int trt_set_light_grids(trt_context *ctx, int directional_cells, int 
     trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
     const int rc = build_tables(ctx, cs, ctx->scene.ground);
     return rc ? rc : refresh_occupancy(ctx);
+}
+
+extern "C" int trt_set_light_slabs(trt_context *ctx, int directional_slabs, int point_shells)
+{
+    if (!ctx || directional_slabs < 1 || point_shells < 1 || directional_slabs > 64 || point_shells > 64)
+        return fail(TRT_ERR_ARGUMENT, "light slabs %d, %d", directional_slabs, point_shells);
+    ctx->dirgrid_slabs = directional_slabs;
+    ctx->pointgrid_shells = point_shells;
+    return trt_set_light_grids(ctx, ctx->dirgrid_cells, ctx->pointgrid_cells);
 }
 
 extern "C" int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_cells)

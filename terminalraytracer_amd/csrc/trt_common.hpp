@@ -82,7 +82,7 @@ struct CullView
 };
 
 constexpr int kLdsCameraDoubles = 13;                       // basis x,y,z (9) eye (3) -screen_distance (1)
-constexpr int kDirGridDoubles = 10, kPointGridDoubles = 8;  // sizeof(trt_dirgrid) / 8, sizeof(trt_pointgrid) / 8 (asserted in trt_rounds.hpp)
+constexpr int kDirGridDoubles = 14, kPointGridDoubles = 9;  // sizeof(trt_dirgrid) / 8, sizeof(trt_pointgrid) / 8 (asserted in trt_rounds.hpp)
 
 // TRT.c:1063-1066 for frames rendered with samples as work units: pixel = (((0 + s0) + s1) + ...) * (1/spp),
 // samples in index order.  The scratch is sample-major, samples[(k*pixels + pixel)*3 + channel], so that for every k

@@ -66,6 +66,18 @@
  *     likewise with q := 2 a t (TRT.c:685: t > 1e-5).  Mg = |l|_inf + 2 rg bounds every coordinate of an origin the table admits
  *     and of a hit point nearer than the light (farther hit points only enter "beyond", where their own size drowns the nudge);
  *     if Mg > 2^28, dark_floor = +inf: lo = -1, hi = +inf, every hit is unsure (the closest-hit search, always).
+ * (5) DEPTH (round 4).  The tables have a third coordinate -- `slabs` slabs of depth along a directional light's direction,
+ *     `shells` shells of distance from a point light -- and a cell lists only the spheres that can matter to an origin of ITS slab.
+ *     Directional: the exact test reports a hit only with t0 > 0, i.e. -b > sqrt(disc) >= 0, i.e. (c - o).d > 0 up to the
+ *     rounding of that dot product (<= 2^-50 M): the sphere's CENTRE is ahead of the origin.  Slab s (s > 0) therefore holds the
+ *     spheres whose centre's depth, plus delta for the FP32 look-up of the origin's depth (the same 10 eps rg as the plane
+ *     coordinates), reaches the slab's lower edge, the edge lowered by 0.01 slab for the rounding of the slab coordinate; slab 0
+ *     holds every sphere of the column (origins below the grid clamp into it), origins above the grid clamp into the top slab.
+ *     Point: a hit nearer than the light lies at distance < R_o = |o - l| from it, so it can only be on a sphere with
+ *     |c - l| - rho < R_o; a sphere with |c - l| - rho >= R_o + near has every point >= near farther from the light than the
+ *     origin is: the ray meets it, if at all, beyond the light by >= near -- the case (3) shows to be "lit" whether listed or not.
+ *     Shell s (not the outermost) holds the spheres with |c - l| - rho - near - delta below the shell's outer radius, the
+ *     radius raised by 0.01 shell; the outermost shell holds every sphere of the cone (origins farther away clamp into it).
  *     tests/test_lightgrid.py drives this very classification with the oracle's shadow rays and adversarial ones: every
  *     "dark" and every "lit" it returns must be the reference's answer.
  */
@@ -89,8 +101,14 @@ typedef struct
     float inv_cell;     /* cells per unit length */
     float g_max;        /* g - 1 */
     float rg2;          /* admissible |o - g0|^2 */
+    float e3[3];        /* FP32 unit vector towards the light: depth = (o - g0).e3 */
+    float w0;           /* depth of the lowest slab's lower edge */
+    float inv_slab;     /* slabs per unit depth */
+    float s_max;        /* slabs - 1 */
     int g;              /* cells per side */
+    int slabs;          /* slabs of depth (5): the table has slabs * g * g cells, cell = (slab * g + row) * g + column */
     int words;          /* 64-bit words per cell = ceil(n / 64) */
+    int pad_;
 } trt_dirgrid;
 
 typedef struct
@@ -101,7 +119,10 @@ typedef struct
     float half_g; /* g / 2 */
     float g_max;  /* g - 1 */
     float rg2;    /* admissible |o - l|^2 */
+    float inv_shell; /* shells per unit distance from the light */
+    float s_max;     /* shells - 1 */
     int g;        /* cells per face side */
+    int shells;   /* shells of distance from the light (5): shells * 6 * g * g cells, cell = ((shell * 6 + face) * g + row) * g + column */
     int words;
 } trt_pointgrid;
 
@@ -131,7 +152,9 @@ TRT_HD int trt_dirgrid_cell(const trt_dirgrid *G, double ox, double oy, double o
     float cu = (u - G->u0) * G->inv_cell, cv = (v - G->v0) * G->inv_cell;
     cu = __builtin_fminf(__builtin_fmaxf(cu, 0.0f), G->g_max);
     cv = __builtin_fminf(__builtin_fmaxf(cv, 0.0f), G->g_max);
-    return (int)cv * G->g + (int)cu;
+    const float w = __builtin_fmaf(z, G->e3[2], __builtin_fmaf(y, G->e3[1], x * G->e3[0]));
+    const float cs = __builtin_fminf(__builtin_fmaxf((w - G->w0) * G->inv_slab, 0.0f), G->s_max); /* NaN -> 0: the slab that holds everything */
+    return ((int)cs * G->g + (int)cv) * G->g + (int)cu;
 }
 
 TRT_HD int trt_pointgrid_cell(const trt_pointgrid *G, double ox, double oy, double oz, int *far)
@@ -158,7 +181,9 @@ TRT_HD int trt_pointgrid_cell(const trt_pointgrid *G, double ox, double oy, doub
     float cu = __builtin_fmaf(pu * inv, G->half_g, G->half_g), cv = __builtin_fmaf(pv * inv, G->half_g, G->half_g);
     cu = __builtin_fminf(__builtin_fmaxf(cu, 0.0f), G->g_max);
     cv = __builtin_fminf(__builtin_fmaxf(cv, 0.0f), G->g_max);
-    return (face * G->g + (int)cv) * G->g + (int)cu;
+    /* shell of the origin's distance from the light; min(x, s_max) with x first: NaN -> the outermost shell, which holds everything */
+    const float cs = __builtin_fminf(__builtin_sqrtf(r2) * G->inv_shell, G->s_max);
+    return (((int)cs * 6 + face) * G->g + (int)cv) * G->g + (int)cu;
 }
 
 /* ------------------------------------------------ builders ------------------------------------------------
@@ -174,6 +199,7 @@ TRT_HD void trt_lightgrid_set(unsigned long long *cell, int sphere) { cell[spher
 typedef struct
 {
     double pu, pv, rad;
+    double zs; /* (5): depth of the centre, grown by delta, in SLAB units above the lowest slab's lower edge */
 } trt_dirgrid_disc;
 
 /* a sphere as a point light's cube map sees it: unit axis light -> centre, sine and cosine of the grown half-angle */
@@ -182,6 +208,7 @@ typedef struct
     double a[3];
     double sin_a, cos_a;
     double everywhere; /* != 0: the light is inside or next to the sphere, every cell holds it */
+    double shell_lo;   /* (5), point lights only: |c - l| - rho - near - delta in SHELL units: the sphere matters from this shell outwards */
 } trt_pointgrid_cone;
 
 /* does the disc reach cell (c, j), the cell grown by 0.01 on every side? */
@@ -192,6 +219,11 @@ TRT_HD int trt_dirgrid_reaches(const trt_dirgrid_disc *s, int c, int j)
     const double ny = s->pv < y0 ? y0 - s->pv : (s->pv > y1 ? s->pv - y1 : 0.0);
     return nx * nx + ny * ny <= s->rad * s->rad;
 }
+
+/* (5): does the sphere matter to origins of slab s of `slabs`?  Slab 0 holds every sphere of its column. */
+TRT_HD int trt_dirgrid_in_slab(const trt_dirgrid_disc *s, int slab) { return slab == 0 || s->zs >= (double)slab - 0.01; }
+/* (5): ... to origins of shell s of `shells`?  The outermost shell holds every sphere of its cone. */
+TRT_HD int trt_pointgrid_in_shell(const trt_pointgrid_cone *s, int shell, int shells) { return shell == shells - 1 || s->shell_lo <= (double)shell + 1.01; }
 
 /* tangent of (45 degrees + 1e-4 rad) and a little more: how far an edge cell stretches past the face's edge */
 #define TRT_POINTGRID_EDGE 1.00021
@@ -239,9 +271,11 @@ TRT_HD int trt_pointgrid_reaches(const trt_pointgrid_cone *s, int face, int c, i
 
 /* Directional light with to-light direction `to_light` (TRT.c:903-904; normalised here).  Fills G and one disc per
  * sphere (`discs` must hold n).  cs: the culling table's scene constants (shift and bounds). */
-static inline void trt_dirgrid_prepare(const double *spheres, int n, const trt_cull_scene *cs, const double to_light[3], int g, trt_dirgrid *G,
-                                       trt_dirgrid_disc *discs)
+static inline void trt_dirgrid_prepare(const double *spheres, int n, const trt_cull_scene *cs, const double to_light[3], int g, int slabs,
+                                       trt_dirgrid *G, trt_dirgrid_disc *discs)
 {
+    if (slabs < 1)
+        slabs = 1;
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
     const double reach = (double)cs->cn + (double)cs->rm;
     const double rg = TRT_LIGHTGRID_RANGE * reach + 1.0;
@@ -263,15 +297,18 @@ static inline void trt_dirgrid_prepare(const double *spheres, int n, const trt_c
     for (int k = 0; k < 3; k++)
         e1[k] /= e1l;
     const double e2[3] = {d[1] * e1[2] - d[2] * e1[1], d[2] * e1[0] - d[0] * e1[2], d[0] * e1[1] - d[1] * e1[0]};
-    /* discs in plane coordinates: centre, radius rho + delta */
-    double lo[2] = {0, 0}, hi[2] = {0, 0};
+    /* discs in plane coordinates: centre, radius rho + delta; depth of the centre along the light direction */
+    double lo[2] = {0, 0}, hi[2] = {0, 0}, zlo = 0, zhi = 0;
     for (int i = 0; i < n; i++)
     {
         const double *s = spheres + 9 * i;
         const double C[3] = {s[0] - cs->c0[0], s[1] - cs->c0[1], s[2] - cs->c0[2]};
         const double pu = C[0] * e1[0] + C[1] * e1[1] + C[2] * e1[2], pv = C[0] * e2[0] + C[1] * e2[1] + C[2] * e2[2];
         const double rad = __builtin_sqrt(s[3] * s[3] + E) + delta;
-        discs[i].pu = pu, discs[i].pv = pv, discs[i].rad = rad;
+        const double z = C[0] * d[0] + C[1] * d[1] + C[2] * d[2];
+        discs[i].pu = pu, discs[i].pv = pv, discs[i].rad = rad, discs[i].zs = z;
+        zlo = (i == 0 || z < zlo) ? z : zlo;
+        zhi = (i == 0 || z > zhi) ? z : zhi;
         lo[0] = (i == 0 || pu - rad < lo[0]) ? pu - rad : lo[0];
         hi[0] = (i == 0 || pu + rad > hi[0]) ? pu + rad : hi[0];
         lo[1] = (i == 0 || pv - rad < lo[1]) ? pv - rad : lo[1];
@@ -295,26 +332,41 @@ static inline void trt_dirgrid_prepare(const double *spheres, int n, const trt_c
     G->rg2 = (float)(rg * rg * (1.0 - 1e-6));
     G->g = g;
     G->words = words;
+    G->pad_ = 0;
+    /* (5) slabs of depth over the centres' range (origins ahead of every centre clamp into the top slab, whose columns are short) */
+    double zext = zhi - zlo;
+    if (!(zext > 1e-9))
+        zext = 1e-9;
+    for (int k = 0; k < 3; k++)
+        G->e3[k] = (float)d[k];
+    G->w0 = (float)zlo;
+    G->inv_slab = (float)((double)slabs / zext);
+    G->s_max = (float)(slabs - 1);
+    G->slabs = slabs;
     const double inv = (double)G->inv_cell, u0 = (double)G->u0, v0 = (double)G->v0; /* the look-up's own constants */
+    const double w0 = (double)G->w0, inv_slab = (double)G->inv_slab;
     for (int i = 0; i < n; i++)
-    { /* to cell units */
+    { /* to cell units / slab units */
         discs[i].pu = (discs[i].pu - u0) * inv;
         discs[i].pv = (discs[i].pv - v0) * inv;
         discs[i].rad = discs[i].rad * inv;
+        discs[i].zs = (discs[i].zs + delta - w0) * inv_slab;
     }
 }
 
 /* Point light at `light` (TRT.c:930).  Fills G and one cone per sphere (`cones` must hold n). */
-static inline void trt_pointgrid_prepare(const double *spheres, int n, const trt_cull_scene *cs, const double light[3], int g, trt_pointgrid *G,
-                                         trt_pointgrid_cone *cones)
+static inline void trt_pointgrid_prepare(const double *spheres, int n, const trt_cull_scene *cs, const double light[3], int g, int shells,
+                                         trt_pointgrid *G, trt_pointgrid_cone *cones)
 {
+    if (shells < 1)
+        shells = 1;
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
     const double reach = (double)cs->cn + (double)cs->rm;
     const double lc[3] = {light[0] - cs->c0[0], light[1] - cs->c0[1], light[2] - cs->c0[2]};
     const double away = __builtin_sqrt(lc[0] * lc[0] + lc[1] * lc[1] + lc[2] * lc[2]); /* light to the scene's centre */
     const double rg = TRT_LIGHTGRID_RANGE * (reach + away) + 1.0;
     const double M = rg + away + reach;
-    const double E = 0x1p-37 * M * M, near = 0.02 + 4e-6 * rg;
+    const double E = 0x1p-37 * M * M, near = 0.02 + 4e-6 * rg, delta = 3e-6 * rg;
     const double sin_grow = 1.0000000000e-5, cos_grow = 0.99999999995; /* sin and cos of the 1e-5 rad the cones grow by */
     for (int k = 0; k < 3; k++)
         G->l[k] = light[k];
@@ -331,6 +383,21 @@ static inline void trt_pointgrid_prepare(const double *spheres, int n, const trt
         G->dark_floor = Mg <= 0x1p28 ? 0x1p-60 * Mg * Mg : __builtin_inf(); /* also +inf for NaN */
         G->e2 = 0x1p-48 * Mg * (rg + Mg);
     }
+    /* (5) shells of distance from the light, out to the farthest sphere (origins farther away clamp into the outermost shell) */
+    double far_d = 0.0;
+    for (int i = 0; i < n; i++)
+    {
+        const double *s = spheres + 9 * i;
+        const double a[3] = {s[0] - light[0], s[1] - light[1], s[2] - light[2]};
+        const double D = __builtin_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) + __builtin_fabs(s[3]);
+        far_d = D > far_d ? D : far_d; /* NaN: stays */
+    }
+    if (!(far_d > 1e-9))
+        far_d = 1e-9;
+    G->inv_shell = (float)((double)shells / far_d);
+    G->s_max = (float)(shells - 1);
+    G->shells = shells;
+    const double inv_shell = (double)G->inv_shell;
     for (int i = 0; i < n; i++)
     {
         const double *s = spheres + 9 * i;
@@ -338,6 +405,7 @@ static inline void trt_pointgrid_prepare(const double *spheres, int n, const trt
         const double D = __builtin_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
         const double rho = __builtin_sqrt(s[3] * s[3] + E) + 0x1p-45 * M;
         trt_pointgrid_cone *c = cones + i;
+        c->shell_lo = (D - rho - near - delta) * inv_shell;
         c->everywhere = (!(D > rho + near) || !(rho / D < 0.999999)) ? 1.0 : 0.0; /* the light is inside or next to the sphere */
         if (c->everywhere != 0.0)
         {
@@ -357,19 +425,19 @@ static inline void trt_pointgrid_prepare(const double *spheres, int n, const trt
 }
 
 /* Host reference builders (tests; the library builds the same tables on the device).  Return the bits set. */
-static inline long trt_dirgrid_build(const double *spheres, int n, const trt_cull_scene *cs, const double to_light[3], int g, trt_dirgrid *G,
+static inline long trt_dirgrid_build(const double *spheres, int n, const trt_cull_scene *cs, const double to_light[3], int g, int slabs, trt_dirgrid *G,
                                      unsigned long long *masks, trt_dirgrid_disc *discs)
 {
-    trt_dirgrid_prepare(spheres, n, cs, to_light, g, G, discs);
+    trt_dirgrid_prepare(spheres, n, cs, to_light, g, slabs, G, discs);
     const int words = G->words;
     long bits = 0;
-    for (long cell = 0; cell < (long)g * g; cell++)
+    for (long cell = 0; cell < (long)G->slabs * g * g; cell++)
     {
         unsigned long long *m = masks + cell * words;
         for (int w = 0; w < words; w++)
             m[w] = 0;
         for (int i = 0; i < n; i++)
-            if (trt_dirgrid_reaches(discs + i, (int)(cell % g), (int)(cell / g)))
+            if (trt_dirgrid_in_slab(discs + i, (int)(cell / ((long)g * g))) && trt_dirgrid_reaches(discs + i, (int)(cell % g), (int)((cell / g) % g)))
             {
                 trt_lightgrid_set(m, i);
                 bits++;
@@ -378,20 +446,20 @@ static inline long trt_dirgrid_build(const double *spheres, int n, const trt_cul
     return bits;
 }
 
-static inline long trt_pointgrid_build(const double *spheres, int n, const trt_cull_scene *cs, const double light[3], int g, trt_pointgrid *G,
+static inline long trt_pointgrid_build(const double *spheres, int n, const trt_cull_scene *cs, const double light[3], int g, int shells, trt_pointgrid *G,
                                        unsigned long long *masks, trt_pointgrid_cone *cones)
 {
-    trt_pointgrid_prepare(spheres, n, cs, light, g, G, cones);
+    trt_pointgrid_prepare(spheres, n, cs, light, g, shells, G, cones);
     const int words = G->words;
     long bits = 0;
-    for (long cell = 0; cell < 6L * g * g; cell++)
+    for (long cell = 0; cell < 6L * G->shells * g * g; cell++)
     {
         unsigned long long *m = masks + cell * words;
         for (int w = 0; w < words; w++)
             m[w] = 0;
-        const int face = (int)(cell / ((long)g * g)), j = (int)((cell / g) % g), c = (int)(cell % g);
+        const int shell = (int)(cell / (6L * g * g)), face = (int)((cell / ((long)g * g)) % 6), j = (int)((cell / g) % g), c = (int)(cell % g);
         for (int i = 0; i < n; i++)
-            if (trt_pointgrid_reaches(cones + i, face, c, j, g))
+            if (trt_pointgrid_in_shell(cones + i, shell, G->shells) && trt_pointgrid_reaches(cones + i, face, c, j, g))
             {
                 trt_lightgrid_set(m, i);
                 bits++;

@@ -71,6 +71,7 @@ SYMBOLS = {
     "trt_read_diagnostics": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "trt_set_kernel": (_I, [_VP, _I]),
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
+    "trt_set_light_slabs": (_I, [_VP, _I, _I]),
     "trt_set_path_grids": (_I, [_VP, _I, _I]),
     "trt_set_path_grids_min_spheres": (_I, [_VP, _I]),
     "trt_set_path_patches": (_I, [_VP, _I]),
@@ -196,6 +197,10 @@ class Context:
     def set_light_grids(self, directional_cells, point_cells):
         """cells per side of the light-space candidate tables; 0, 0 = off (trt_set_light_grids)"""
         _check(lib().trt_set_light_grids(self._h, directional_cells, point_cells))
+
+    def set_light_slabs(self, directional_slabs, point_shells):
+        """the light tables' depth coordinate: slabs along a directional light, shells about a point light (trt_set_light_slabs)"""
+        _check(lib().trt_set_light_slabs(self._h, directional_slabs, point_shells))
 
     def set_path_grids(self, eye_cells, sphere_cells):
         """cells per cube-map face side of the path rays' family tables; 0, 0 = off (trt_set_path_grids)"""

@@ -59,7 +59,7 @@ static void tally(grid_stats *st, unsigned cand, unsigned *group_max, size_t r, 
 }
 
 /* all rays share the direction rays[3..5] (the unit to-light vector) */
-void dirgrid_check(const double *spheres, int n, const double *rays, size_t n_rays, int g, grid_stats *st)
+void dirgrid_check(const double *spheres, int n, const double *rays, size_t n_rays, int g, int slabs, grid_stats *st)
 {
     memset(st, 0, sizeof *st);
     if (!n_rays)
@@ -69,19 +69,22 @@ void dirgrid_check(const double *spheres, int n, const double *rays, size_t n_ra
     trt_cull_scene cs;
     trt_cull_build(spheres, n, 8, table, &cs);
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
-    unsigned long long *masks = (unsigned long long *)malloc(sizeof(unsigned long long) * (size_t)g * g * words);
+    if (slabs < 1)
+        slabs = 1;
+    unsigned long long *masks = (unsigned long long *)malloc(sizeof(unsigned long long) * (size_t)slabs * g * g * words);
     trt_dirgrid G;
     trt_dirgrid_disc *discs = (trt_dirgrid_disc *)malloc(sizeof(trt_dirgrid_disc) * (size_t)(n ? n : 1));
-    st->bits_set = (unsigned long long)trt_dirgrid_build(spheres, n, &cs, rays + 3, g, &G, masks, discs);
+    st->bits_set = (unsigned long long)trt_dirgrid_build(spheres, n, &cs, rays + 3, g, slabs, &G, masks, discs);
     free(discs);
-    st->cells = (unsigned long long)g * g;
+    st->cells = (unsigned long long)slabs * g * g;
     /* the clamp relies on an empty border */
-    for (int j = 0; j < g; j++)
-        for (int c = 0; c < g; c++)
-            if (j == 0 || c == 0 || j == g - 1 || c == g - 1)
-                for (int w = 0; w < words; w++)
-                    if (masks[((size_t)j * g + c) * words + w])
-                        st->violations += 1000000;
+    for (int s = 0; s < slabs; s++)
+        for (int j = 0; j < g; j++)
+            for (int c = 0; c < g; c++)
+                if (j == 0 || c == 0 || j == g - 1 || c == g - 1)
+                    for (int w = 0; w < words; w++)
+                        if (masks[(((size_t)s * g + j) * g + c) * words + w])
+                            st->violations += 1000000;
     unsigned group_max = 0;
     for (size_t r = 0; r < n_rays; r++)
     {
@@ -95,7 +98,7 @@ void dirgrid_check(const double *spheres, int n, const double *rays, size_t n_ra
             st->far++;
             continue;
         }
-        if (cell < 0 || cell >= g * g)
+        if (cell < 0 || cell >= slabs * g * g)
         {
             note(st, o, -1, cell);
             continue;
@@ -151,7 +154,7 @@ static int decide_lit(const double *spheres, int n, const unsigned long long *m,
     return light_d2 < nudged_d2(o, d, best_t);
 }
 
-void pointgrid_check(const double *spheres, int n, const double *light, const double *rays, size_t n_rays, int g, grid_stats *st)
+void pointgrid_check(const double *spheres, int n, const double *light, const double *rays, size_t n_rays, int g, int shells, grid_stats *st)
 {
     memset(st, 0, sizeof *st);
     const int padded = trt_cull_padded(n, 8);
@@ -159,12 +162,14 @@ void pointgrid_check(const double *spheres, int n, const double *light, const do
     trt_cull_scene cs;
     trt_cull_build(spheres, n, 8, table, &cs);
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
-    unsigned long long *masks = (unsigned long long *)malloc(sizeof(unsigned long long) * 6 * (size_t)g * g * words);
+    if (shells < 1)
+        shells = 1;
+    unsigned long long *masks = (unsigned long long *)malloc(sizeof(unsigned long long) * 6 * (size_t)shells * g * g * words);
     trt_pointgrid G;
     trt_pointgrid_cone *cones = (trt_pointgrid_cone *)malloc(sizeof(trt_pointgrid_cone) * (size_t)(n ? n : 1));
-    st->bits_set = (unsigned long long)trt_pointgrid_build(spheres, n, &cs, light, g, &G, masks, cones);
+    st->bits_set = (unsigned long long)trt_pointgrid_build(spheres, n, &cs, light, g, shells, &G, masks, cones);
     free(cones);
-    st->cells = 6ull * g * g;
+    st->cells = 6ull * shells * g * g;
     const double near = 0.02 + 4e-6 * sqrt((double)G.rg2);
     unsigned group_max = 0;
     for (size_t r = 0; r < n_rays; r++)
@@ -179,7 +184,7 @@ void pointgrid_check(const double *spheres, int n, const double *light, const do
             st->far++;
             continue;
         }
-        if (cell < 0 || cell >= 6 * g * g)
+        if (cell < 0 || cell >= 6 * shells * g * g)
         {
             note(st, o, -1, cell);
             continue;
@@ -302,7 +307,7 @@ static int anyhit_class(const double *spheres, int n, const unsigned long long *
 }
 
 void pointgrid_anyhit_check(const double *spheres, int n, const double *ground, const double *light, const double *rays, size_t n_rays, int g,
-                            anyhit_stats *st)
+                            int shells, anyhit_stats *st)
 {
     memset(st, 0, sizeof *st);
     const int padded = trt_cull_padded(n, 8);
@@ -310,10 +315,12 @@ void pointgrid_anyhit_check(const double *spheres, int n, const double *ground, 
     trt_cull_scene cs;
     trt_cull_build(spheres, n, 8, table, &cs);
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
-    unsigned long long *masks = (unsigned long long *)malloc(sizeof(unsigned long long) * 6 * (size_t)g * g * words);
+    if (shells < 1)
+        shells = 1;
+    unsigned long long *masks = (unsigned long long *)malloc(sizeof(unsigned long long) * 6 * (size_t)shells * g * g * words);
     trt_pointgrid G;
     trt_pointgrid_cone *cones = (trt_pointgrid_cone *)malloc(sizeof(trt_pointgrid_cone) * (size_t)(n ? n : 1));
-    trt_pointgrid_build(spheres, n, &cs, light, g, &G, masks, cones);
+    trt_pointgrid_build(spheres, n, &cs, light, g, shells, &G, masks, cones);
     free(cones);
     for (size_t r = 0; r < n_rays; r++)
     {
@@ -322,7 +329,7 @@ void pointgrid_anyhit_check(const double *spheres, int n, const double *ground, 
         int far;
         const int cell = trt_pointgrid_cell(&G, o[0], o[1], o[2], &far);
         st->rays++;
-        if (far || !(fabs(a - 1.0) <= 9.094947017729282e-13) || cell < 0 || cell >= 6 * g * g)
+        if (far || !(fabs(a - 1.0) <= 9.094947017729282e-13) || cell < 0 || cell >= 6 * shells * g * g)
         {
             st->far++;
             continue;
@@ -351,8 +358,9 @@ void pointgrid_anyhit_check(const double *spheres, int n, const double *ground, 
 }
 
 /* The tables themselves, as the host reference builders make them (the GPU tests compare the device-built tables).
- * kind 0: directional light with to-light direction v, masks g*g*words; kind 1: point light at v, masks 6*g*g*words. */
-long lightgrid_host_table(const double *spheres, int n, int kind, const double *v, int g, unsigned long long *masks)
+ * kind 0: directional light with to-light direction v, masks slabs*g*g*words; kind 1: point light at v, masks slabs*6*g*g*words
+ * (`slabs` = slabs of depth resp. shells of distance, trt_lightgrid.h (5)). */
+long lightgrid_host_table(const double *spheres, int n, int kind, const double *v, int g, int slabs, unsigned long long *masks)
 {
     const int padded = trt_cull_padded(n, 8);
     float *table = (float *)malloc(sizeof(float) * 4 * (size_t)(padded ? padded : 1));
@@ -364,14 +372,14 @@ long lightgrid_host_table(const double *spheres, int n, int kind, const double *
     {
         trt_dirgrid G;
         trt_dirgrid_disc *discs = (trt_dirgrid_disc *)malloc(sizeof(trt_dirgrid_disc) * (size_t)(n ? n : 1));
-        bits = trt_dirgrid_build(spheres, n, &cs, v, g, &G, masks, discs);
+        bits = trt_dirgrid_build(spheres, n, &cs, v, g, slabs, &G, masks, discs);
         free(discs);
     }
     else
     {
         trt_pointgrid G;
         trt_pointgrid_cone *cones = (trt_pointgrid_cone *)malloc(sizeof(trt_pointgrid_cone) * (size_t)(n ? n : 1));
-        bits = trt_pointgrid_build(spheres, n, &cs, v, g, &G, masks, cones);
+        bits = trt_pointgrid_build(spheres, n, &cs, v, g, slabs, &G, masks, cones);
         free(cones);
     }
     return bits;

@@ -672,7 +672,8 @@ def test_rgb8_sharded_renderer_feeds_the_emitter(ctx):
     assert em.bytes() == zlib.decompress(open(T.GOLDEN + "/emit_demo_160x48_b4.bin.z", "rb").read())
 
 
-@pytest.mark.parametrize("cells", [(0, 0), (8, 2), (33, 7), (512, 256)], ids=["off", "coarsest", "odd", "fine"])
+@pytest.mark.parametrize("cells", [(0, 0, 16, 16), (8, 2, 1, 1), (33, 7, 5, 3), (512, 256, 16, 16), (128, 64, 64, 64), (128, 64, 1, 1)],
+                         ids=["off", "coarsest", "odd", "fine", "64 slabs", "no depth"])
 def test_light_space_tables_never_change_a_frame(ctx, cells):
     """The production kernel reads a shadow ray's candidate spheres from per-light tables (csrc/trt_lightgrid.h).  Whatever
     their resolution -- or with the tables off, every shadow ray sweeping -- frames must equal the oracle bit for bit:
@@ -689,10 +690,12 @@ def test_light_space_tables_never_change_a_frame(ctx, cells):
     try:
         for scene, w, h, b, spp in cases:
             want, _ = T.oracle_render(scene, w, h, b, spp)
-            ctx.set_light_grids(*cells)
+            ctx.set_light_slabs(*cells[2:])  # the tables' depth coordinate (trt_lightgrid.h (5))
+            ctx.set_light_grids(*cells[:2])
             got = render(ctx, scene, w, h, b, spp)
             assert np.array_equal(bits(got), bits(want)), (cells, len(scene.spheres))
     finally:
+        ctx.set_light_slabs(16, 16)
         ctx.set_light_grids(128, 64)
 
 
@@ -940,7 +943,7 @@ def test_device_built_light_tables_equal_the_host_reference_builder(ctx):
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-I" + inc, "-o", so,
                            os.path.join(T.ROOT, "tests", "lightgrid_check.c"), "-lm"])
     lib = C.CDLL(so)
-    lib.lightgrid_host_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.lightgrid_host_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.lightgrid_host_table.restype = C.c_long
     base = S.synth_scene(40, T.sky("synth"), T.bench_camera(32, 18), seed=5)
     c, r = base.spheres[3, :3], base.spheres[3, 3]
@@ -953,18 +956,21 @@ def test_device_built_light_tables_equal_the_host_reference_builder(ctx):
         for scene in scenes:
             sph = np.ascontiguousarray(scene.spheres, dtype=np.float64)
             n, words = len(sph), max(1, (len(sph) + 63) // 64)
-            for gd, gp in ((128, 64), (19, 5)):
+            # cells per side, and the tables' depth coordinate (slabs along a directional light, shells about a point light)
+            for gd, gp, sd, sp in ((128, 64, 16, 16), (19, 5, 1, 1), (33, 9, 7, 3)):
                 ctx.set_scene(scene)
+                ctx.set_light_slabs(sd, sp)
                 ctx.set_light_grids(gd, gp)
-                for kind, count, g, cells in ((0, len(scene.dir_lights), gd, gd * gd), (1, len(scene.point_lights), gp, 6 * gp * gp)):
+                for kind, count, g, depth, cells in ((0, len(scene.dir_lights), gd, sd, sd * gd * gd), (1, len(scene.point_lights), gp, sp, sp * 6 * gp * gp)):
                     for i in range(count):
                         v = np.ascontiguousarray(-scene.dir_lights[i, :3] if kind == 0 else scene.point_lights[i, :3], dtype=np.float64)
                         want = np.zeros(cells * words, dtype=np.uint64)
-                        bits = lib.lightgrid_host_table(sph.ctypes.data, n, kind, v.ctypes.data, g, want.ctypes.data)
+                        bits = lib.lightgrid_host_table(sph.ctypes.data, n, kind, v.ctypes.data, g, depth, want.ctypes.data)
                         got = ctx.read_light_grid(kind, i, cells * words)
                         assert bits > 0 and len(got) == cells * words
                         assert np.array_equal(got, want), (n, kind, i, g, int((got != want).sum()))
     finally:
+        ctx.set_light_slabs(16, 16)
         ctx.set_light_grids(128, 64)
 
 

@@ -40,40 +40,40 @@ def checker():
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-I" + inc, "-o", so, src, "-lm"])
     lib = C.CDLL(so)
-    lib.dirgrid_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Stats)]
+    lib.dirgrid_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(Stats)]
     lib.dirgrid_check.restype = None
-    lib.pointgrid_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Stats)]
+    lib.pointgrid_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(Stats)]
     lib.pointgrid_check.restype = None
-    lib.pointgrid_anyhit_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(AnyHitStats)]
+    lib.pointgrid_anyhit_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(AnyHitStats)]
     lib.pointgrid_anyhit_check.restype = None
     return lib
 
 
-def run_anyhit(checker, spheres, ground, light, rays, g):
+def run_anyhit(checker, spheres, ground, light, rays, g, shells=16):
     spheres = np.ascontiguousarray(spheres, dtype=np.float64).reshape(-1, 9)
     rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
     light = np.ascontiguousarray(light, dtype=np.float64)
     ground = None if ground is None else np.ascontiguousarray(ground, dtype=np.float64)
     st = AnyHitStats()
     checker.pointgrid_anyhit_check(spheres.ctypes.data, spheres.shape[0], None if ground is None else ground.ctypes.data, light.ctypes.data,
-                                   rays.ctypes.data, rays.shape[0], g, C.byref(st))
+                                   rays.ctypes.data, rays.shape[0], g, shells, C.byref(st))
     return st
 
 
-def run_dir(checker, spheres, rays, g):
+def run_dir(checker, spheres, rays, g, slabs=16):
     spheres = np.ascontiguousarray(spheres, dtype=np.float64).reshape(-1, 9)
     rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
     st = Stats()
-    checker.dirgrid_check(spheres.ctypes.data, spheres.shape[0], rays.ctypes.data, rays.shape[0], g, C.byref(st))
+    checker.dirgrid_check(spheres.ctypes.data, spheres.shape[0], rays.ctypes.data, rays.shape[0], g, slabs, C.byref(st))
     return st
 
 
-def run_point(checker, spheres, light, rays, g):
+def run_point(checker, spheres, light, rays, g, shells=16):
     spheres = np.ascontiguousarray(spheres, dtype=np.float64).reshape(-1, 9)
     rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
     light = np.ascontiguousarray(light, dtype=np.float64)
     st = Stats()
-    checker.pointgrid_check(spheres.ctypes.data, spheres.shape[0], light.ctypes.data, rays.ctypes.data, rays.shape[0], g, C.byref(st))
+    checker.pointgrid_check(spheres.ctypes.data, spheres.shape[0], light.ctypes.data, rays.ctypes.data, rays.shape[0], g, shells, C.byref(st))
     return st
 
 
@@ -89,22 +89,22 @@ FRAMES = [("north-star scene, 64 spheres", lambda: S.synth_scene(64, T.sky("synt
           ("256 spheres", lambda: S.synth_scene(256, T.sky("synth"), T.bench_camera(96, 54)), 96, 54, 12)]
 
 
-@pytest.mark.parametrize("g", [16, 128])
+@pytest.mark.parametrize("g,depth", [(16, 1), (128, 16), (32, 7), (64, 64)])
 @pytest.mark.parametrize("name,make,w,h,b", FRAMES, ids=[f[0] for f in FRAMES])
-def test_masks_hold_every_hit_of_real_frames(checker, name, make, w, h, b, g):
+def test_masks_hold_every_hit_of_real_frames(checker, name, make, w, h, b, g, depth):
     scene = make()
     rays, kinds = traced_rays(scene, w, h, b, 10)
     shadow = rays[kinds == 1]
     assert len(shadow) > 10000 and np.all(shadow[:, 3:] == shadow[0, 3:])
-    st = run_dir(checker, scene.spheres, shadow, g)
-    print(name, "directional", g, describe(st))
+    st = run_dir(checker, scene.spheres, shadow, g, depth)
+    print(name, "directional", g, depth, describe(st))
     assert st.violations == 0, list(st.first_violation)
     assert st.exact_hits > 100 and st.far < 0.02 * st.rays
     assert st.candidates < 0.25 * (st.rays - st.far) * len(scene.spheres)
     point = rays[kinds == 2]
     assert len(point) > 10000
-    st = run_point(checker, scene.spheres, scene.point_lights[0, :3], point, g)
-    print(name, "point", g, describe(st))
+    st = run_point(checker, scene.spheres, scene.point_lights[0, :3], point, g, depth)
+    print(name, "point", g, depth, describe(st))
     assert st.violations == 0, list(st.first_violation)
     assert st.decision_mismatches == 0
     assert st.exact_hits > 100 and st.far < 0.02 * st.rays
@@ -146,9 +146,9 @@ def test_directional_masks_are_conservative_on_adversarial_origins(checker):
         back = rng.uniform(0.1, 100.0, (m, 1)) * scale * rng.choice([1.0, 1.0, 30.0], (m, 1))  # some origins beyond the admissible radius
         o = sph[k, :3] + perp * (sph[k, 3] * (1 + offs))[:, None] - d * back
         rays = np.concatenate([o, np.broadcast_to(d, (m, 3))], axis=1)
-        for g in (8, 64, 256):
-            st = run_dir(checker, sph, rays, g)
-            assert st.violations == 0, (trial, g, list(st.first_violation))
+        for g, slabs in ((8, 3), (64, 16), (256, 1), (32, 64)):
+            st = run_dir(checker, sph, rays, g, slabs)
+            assert st.violations == 0, (trial, g, slabs, list(st.first_violation))
         hits += st.exact_hits
     assert hits > 20000
 
@@ -185,10 +185,10 @@ def test_point_masks_are_conservative_on_adversarial_origins(checker):
         with np.errstate(invalid="ignore", divide="ignore"):
             d = _unit(light - o)
         rays = np.concatenate([o, d], axis=1)
-        for g in (4, 32, 128):
-            st = run_point(checker, sph, light, rays, g)
-            assert st.violations == 0, (trial, g, list(st.first_violation))
-            assert st.decision_mismatches == 0, (trial, g)
+        for g, shells in ((4, 16), (32, 1), (128, 5), (16, 64)):
+            st = run_point(checker, sph, light, rays, g, shells)
+            assert st.violations == 0, (trial, g, shells, list(st.first_violation))
+            assert st.decision_mismatches == 0, (trial, g, shells)
         hits += st.exact_hits
     assert hits > 20000
 
@@ -203,9 +203,9 @@ def test_any_hit_search_decides_as_the_reference_on_real_frames(checker, name, m
     scene = make()
     rays, kinds = traced_rays(scene, w, h, b, 10)
     point = rays[kinds == 2]
-    for g in (16, 64):
-        st = run_anyhit(checker, scene.spheres, scene.ground, scene.point_lights[0, :3], point, g)
-        print(f"\n{name} g {g}: rays {st.rays} far {st.far} dark {st.dark} lit {st.lit} unsure {st.unsure} "
+    for g, shells in ((16, 1), (64, 16)):
+        st = run_anyhit(checker, scene.spheres, scene.ground, scene.point_lights[0, :3], point, g, shells)
+        print(f"\n{name} g {g} shells {shells}: rays {st.rays} far {st.far} dark {st.dark} lit {st.lit} unsure {st.unsure} "
               f"tests any-hit {st.tests / max(1, st.rays - st.far):.3f} closest-hit {st.tests_closest / max(1, st.rays - st.far):.3f}")
         assert st.wrong_dark == 0 and st.wrong_lit == 0, list(st.first_wrong)
         assert st.dark > 1000 and st.lit > 1000 and st.far < 0.02 * st.rays
@@ -252,9 +252,9 @@ def test_any_hit_search_on_adversarial_origins(checker):
         with np.errstate(invalid="ignore", divide="ignore"):
             d = _unit(light - o)
         rays = np.concatenate([o, d], axis=1)
-        for g in (8, 64):
-            st = run_anyhit(checker, sph, ground, light, rays, g)
-            assert st.wrong_dark == 0 and st.wrong_lit == 0, (trial, g, list(st.first_wrong))
+        for g, shells in ((8, 1), (64, 16), (16, 40)):
+            st = run_anyhit(checker, sph, ground, light, rays, g, shells)
+            assert st.wrong_dark == 0 and st.wrong_lit == 0, (trial, g, shells, list(st.first_wrong))
         decided += st.dark + st.lit
         unsure += st.unsure
         if np.abs(light).max() + 2 * 256 * 3 * scale > 2.0 ** 28 * 4:
