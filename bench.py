@@ -235,7 +235,9 @@ def other_configs(hip, host, torch, local, depth, tile_rows):
                          "verified": bool(checks) and all(c["ok"] for c in checks), "verification": checks,
                          "kernel": "render_rounds_kernel<false, false, %s%s>" % ("true" if variant["decoupled"] else "false",
                                                                                   ", true" if d.context(0).path_patches()[0] else ""),
-                         "render_kernel_ms_one_at_a_time": render_ms, "scene_setup_s": setup_s}
+                         "render_kernel_ms_one_at_a_time": render_ms, "scene_setup_s": setup_s,
+                         # one copy of the scene's tables per device, whatever the number of frame slots (trt_share_scene)
+                         "scene_tables": d.context(0).scene_info()}
             prof = (committed_profile() or {}).get("config5") if name == "c5" else None
             if prof:
                 out[name]["compute_executed"] = compute_executed(prof.get("compute_executed"), render_ms)
@@ -268,6 +270,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed frame against the reference's hash")
     ap.add_argument("--kernel", type=int, default=0, help="0 production, 1 reference-order (debug)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--rccl-stand-in", action="store_true", help="TEST HOOK: bind the library TRT_RCCL_LIB names in RCCL's place "
+                    "(tests/rccl_stub.cpp: several ranks on one GPU); without this flag the variable is ignored")
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
     ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = the default, 3: the "
                                                          "next frames' workgroups fill the CUs that a frame's tail leaves idle -- on one GPU "
@@ -311,7 +315,9 @@ def main():
     camera_of = lambda step: cameras[step % len(cameras)]  # noqa: E731
     # --backend gloo: several ranks may share one GPU, which RCCL cannot do: the PyTorch-level rehearsal path -- unless
     # TRT_RCCL_LIB names a stand-in for RCCL (tests/rccl_stub.cpp), with which the product path itself runs on one GPU
-    stand_in = os.environ.get("TRT_RCCL_LIB")
+    stand_in = os.environ.get("TRT_RCCL_LIB") if args.rccl_stand_in else None
+    if stand_in:  # test hook: the library honours TRT_RCCL_LIB only when told to, before its first use of RCCL
+        hip.dist_allow_rccl_override(True)
     rehearsal = world > 1 and args.backend != "nccl" and not stand_in
     carrier = f"cuda:{local}" if args.backend == "nccl" else "cpu"  # where torch.distributed's own tensors live
     fallback_reason = None

@@ -2,7 +2,7 @@
  * One process per GPU; every process runs this same program:
  *
  *   trt_dist_demo <skybox-directory> <rank> <world> <id-file> [frames=60] [width=1920] [height=1080] [tile-rows=8]
- *                 [frames-in-flight=2] [device=<rank>] [rgb8=0]
+ *                 [frames-in-flight=2] [device=<rank>] [rgb8=0] [allow-rccl-stand-in=0]
  *
  * Rank 0 writes the communicator id (what ncclGetUniqueId produced) to <id-file>, the other ranks wait for the file: any
  * other way of carrying 128 bytes to the ranks (MPI, a socket) does as well.  Each rank renders its interleaved row tiles
@@ -11,7 +11,9 @@
  * here it prints the frame's fingerprint instead.  Scene and camera are the reference's (TRT.c:1256-1288, :1327-1336).
  * With world = 1 the whole path (communicator, group, assembly kernel) runs on one GPU.  rgb8 = 1: the ranks gather the
  * frame as the 3 bytes per pixel the emitter makes of it (trt_dist_render_rgb8) and rank 0 prints that frame's fingerprint.
- * device: the GPU of this rank (several ranks on one GPU only work with the tests' stand-in for RCCL, TRT_RCCL_LIB). */
+ * device: the GPU of this rank (several ranks on one GPU only work with the tests' stand-in for RCCL: the environment variable
+ * TRT_RCCL_LIB names it, and the last argument must be 1 -- the library ignores the variable unless the process asks for the
+ * override, trt_dist_allow_rccl_override). */
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -39,6 +41,11 @@ int main(int argc, char **argv)
     const int frames = argc > 5 ? atoi(argv[5]) : 60, width = argc > 6 ? atoi(argv[6]) : 1920, height = argc > 7 ? atoi(argv[7]) : 1080;
     const int tile_rows = argc > 8 ? atoi(argv[8]) : 8, in_flight = argc > 9 ? atoi(argv[9]) : 2, device = argc > 10 ? atoi(argv[10]) : rank;
     const int rgb8 = argc > 11 ? atoi(argv[11]) : 0;
+    if (argc > 12 && atoi(argv[12]) && trt_dist_allow_rccl_override(1) != TRT_OK) /* TEST HOOK: before the first use of RCCL */
+    {
+        fprintf(stderr, "trt_dist_allow_rccl_override: %s\n", trt_dist_last_error());
+        return 1;
+    }
 
     Skybox sky;
     int rc = trt_load_skybox(&sky, argv[1]);
@@ -131,8 +138,8 @@ int main(int argc, char **argv)
             fprintf(stderr, "trt_dist_fetch: %s\n", trt_dist_last_error());
             return 1;
         }
-        printf("%d frames %dx%d on %d GPU(s): %.3f ms/frame, last frame %sfnv %016llx\n", frames, width, height, world, 1e3 * elapsed / frames,
-               rgb8 ? "rgb8 " : "", trt_fnv1a64(pixels, bytes));
+        printf("%d frames %dx%d on %d GPU(s): %.3f ms/frame, last frame %sfnv %016llx (gather through %s)\n", frames, width, height, world,
+               1e3 * elapsed / frames, rgb8 ? "rgb8 " : "", trt_fnv1a64(pixels, bytes), world > 1 ? trt_dist_rccl_library() : "nothing: one rank");
         free(pixels);
     }
     trt_dist_destroy(dist);

@@ -109,6 +109,20 @@ int trt_get_stream(trt_context *ctx, void **hip_stream);
  * (Scene layout TRT.c:196-208.)  Synchronous; call once per scene, not per frame. */
 int trt_set_scene(trt_context *ctx, const Scene *scene);
 
+/* `dst` renders the scene `src` was given, FROM src's tables: spheres, lights, cubemap and every candidate table of the scene stay
+ * one copy per device however many contexts render it (the frame slots of a trt_dist render different cameras of one scene at the
+ * same time: TRT.c:1296-1306 builds the scene once, TRT.c:1327-1339 moves the camera per frame).  Only what depends on the camera
+ * -- the two tables of the eye's families -- and the per-frame buffers are dst's own.  Both contexts must be of the same device;
+ * up to 8 contexts per scene.  While tables are shared, the table setters (trt_set_light_grids / _slabs, trt_set_path_grids /
+ * _patches / _min_spheres) refuse on every sharer; trt_set_scene gives a context tables of its own again.  The refraction
+ * extension's indices are per context (dst starts with none). */
+int trt_share_scene(trt_context *dst, trt_context *src);
+/* Device memory held by the scene's primitives and tables (bytes), how many contexts share them, host seconds of the last build. */
+int trt_scene_info(trt_context *ctx, unsigned long long *table_bytes, int *sharers, double *build_seconds);
+/* Tests: cap the scene's part of the pool of long candidate lists at `words` 64-bit words (0 = automatic) from the next
+ * trt_set_scene on; lists that find no room leave their cell without a list and its rays sweep -- frames stay bit-identical. */
+int trt_set_list_pool_words(trt_context *ctx, size_t words);
+
 /* Render the owned rows into DEVICE memory: d_pixels[local_row*width + col] = 3 doubles
  * (the Screen layout of TRT.c:188-193).  Asynchronous on the context's stream.
  * camera: TRT.c:178-184, by value per frame as main() does (TRT.c:1327-1339). */
@@ -281,14 +295,21 @@ const char *trt_version(void);
  * pixel is independent.  Here one rank = one process (or thread) = one GPU; the ranks render interleaved tiles of
  * `tile_rows` rows each (tile t -> rank t mod world) and ONE gather per frame brings the rows to rank 0 over RCCL
  * (ncclSend / ncclRecv inside one group on the library's own stream; over xGMI every peer has its own link to the root).
- * Frames are pipelined over `frames_in_flight` renderer contexts.  RCCL is loaded at run time (librccl.so.1; the environment
- * variable TRT_RCCL_LIB names another library with the same entry points -- the tests' stand-in) and only for world > 1.
+ * Frames are pipelined over `frames_in_flight` renderer contexts.  RCCL is loaded at run time (librccl.so.1) and only for
+ * world > 1.  TEST HOOK: a process that calls trt_dist_allow_rccl_override(1) before its first use of RCCL binds the library the
+ * environment variable TRT_RCCL_LIB names instead (the tests' stand-in, which lets several ranks share one GPU); every other
+ * process ignores the variable.
  * The host program carries the 128-byte id from rank 0 to the other ranks however it likes (MPI, a file, a socket,
  * torch.distributed): it is what ncclGetUniqueId produced. */
 typedef struct trt_dist trt_dist;
 #define TRT_DIST_ID_BYTES 128
 
 int trt_dist_unique_id(void *id_out); /* rank 0 */
+/* TEST HOOK, see above: allow (1) or forbid (0, the default) TRT_RCCL_LIB to name the library bound in RCCL's place.  Fails with
+ * TRT_ERR_NOT_INITIALISED once RCCL has been bound.  trt_dist_rccl_library: the library this process bound ("" before the first
+ * use; "STAND-IN (TRT_RCCL_LIB): <path>" when the override took effect). */
+int trt_dist_allow_rccl_override(int allow);
+const char *trt_dist_rccl_library(void);
 
 /* Collective over the `world` ranks (same id, world, frame size, tile_rows everywhere).  scene: as for trt_set_scene (host
  * pointers inside; every rank holds the whole scene, ~1.5 MB with a 256^2 cubemap).  reserved_cus: compute units the

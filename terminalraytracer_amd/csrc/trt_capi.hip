@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -73,6 +74,11 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+ double host_seconds()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 #define HIP_TRY(expr)                                                                                      \
     do                                                                                                     \
     {                                                                                                      \
@@ -121,6 +127,51 @@ struct DeviceBuffer
 
 } // namespace
 
+// Everything on the device that depends on the SCENE only (primitives, cubemap, every candidate table but the eye's two): built by
+// trt_set_scene, read-only afterwards, and shareable between the contexts of one device (trt_share_scene): the frame slots of a
+// trt_dist render different cameras of ONE scene at the same time.  What depends on the camera -- the two tables of the eye's
+// families and their part of the pool of long lists -- has kEyeSlots places in the same allocations, one per sharing context, so
+// that the kernels keep reading ONE table base and ONE pool base whoever built what.
+constexpr int kEyeSlots = 8; // = the most frames a trt_dist keeps in flight
+
+struct SceneTables
+{
+    int device = 0;
+    DeviceBuffer<double> d_spheres, d_dir, d_point;
+    DeviceBuffer<float> d_cull;
+    // light-space candidate masks (trt_lightgrid.h) and the host copy of the primitives they were built from
+    DeviceBuffer<unsigned long long> d_dir_masks, d_point_masks;
+    DeviceBuffer<trt_dirgrid> d_dirgrids;
+    DeviceBuffer<trt_pointgrid> d_pointgrids;
+    DeviceBuffer<trt_dirgrid_disc> d_discs;   // per directional light and sphere: what the marking kernel reads
+    DeviceBuffer<trt_pointgrid_cone> d_cones; // per point light and sphere
+    // the tables as LIST CELLS (trt_raygrid.h), which is what the kernel reads: one 64-bit word per cell, long lists in d_pool
+    DeviceBuffer<unsigned long long> d_dir_lists, d_point_lists, d_path_lists, d_pool;
+    // 64-bit counters of pool words taken: [0] by the scene's tables, [16 (1 + s)] by the eye's tables of slot s (a cache line apart).
+    // 64 bits: a 32-bit counter that keeps counting after the pool is exhausted wraps, and lists would overwrite one another.
+    DeviceBuffer<unsigned long long> d_pool_used;
+    DeviceBuffer<trt_rayfamily> d_families;    // the 2NP families of the spheres, for the marking kernel
+    DeviceBuffer<double> d_sphere_fam;         // per sphere {mirror centre, |r|}: what the render kernel keeps in LDS
+    DeviceBuffer<double> d_patch_rec;          // per patch {t, rho, mirrored t, rho}: likewise
+    DeviceBuffer<uint32_t> d_sky;
+    int path_built_for[4] = {-1, -1, -1, -2};
+    int grids_built_for[4] = {-1, -1, -1, -1};
+    size_t pool_scene_words = 0, pool_eye_words = 0; // capacities: the scene's part of d_pool, then kEyeSlots parts of pool_eye_words
+    trt_cull_scene cull_scene{};                      // of the spheres the tables were built from
+    double ground_built[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    std::vector<double> h_spheres, h_dir, h_point; // what the tables on the device were built from
+    unsigned eye_slots_taken = 0;                  // bit s: a context renders with the eye tables of slot s
+    double build_seconds = 0.0;                    // host time of the last table build (trt_scene_info)
+    ~SceneTables()
+    {
+        (void)hipSetDevice(device);
+        d_spheres.release(), d_dir.release(), d_point.release(), d_cull.release(), d_dir_masks.release(), d_point_masks.release();
+        d_dirgrids.release(), d_pointgrids.release(), d_discs.release(), d_cones.release(), d_dir_lists.release(), d_point_lists.release();
+        d_path_lists.release(), d_pool.release(), d_pool_used.release(), d_families.release(), d_sphere_fam.release(), d_patch_rec.release();
+        d_sky.release();
+    }
+};
+
 struct trt_context
 {
     int device = 0;
@@ -131,36 +182,20 @@ struct trt_context
     int lds_limit = 0;
 
     bool have_scene = false;
+    std::shared_ptr<SceneTables> T; // never null after init_context; shared after trt_share_scene
+    int eye_slot = 0;               // which of T's kEyeSlots places this context's eye tables live in
     trt::SceneView scene{};
     trt::CullView cull{};
-    DeviceBuffer<double> d_spheres, d_dir, d_point, d_jitter, d_fb, d_axes, d_samples, d_samples_alt;
-    DeviceBuffer<float> d_cull;
-    // light-space candidate masks (trt_lightgrid.h) and the host copy of the primitives they were built from
-    DeviceBuffer<unsigned long long> d_dir_masks, d_point_masks;
-    DeviceBuffer<trt_dirgrid> d_dirgrids;
-    DeviceBuffer<trt_pointgrid> d_pointgrids;
-    DeviceBuffer<trt_dirgrid_disc> d_discs;   // per directional light and sphere: what the marking kernel reads
-    DeviceBuffer<trt_pointgrid_cone> d_cones; // per point light and sphere
+    DeviceBuffer<double> d_jitter, d_fb, d_axes, d_samples, d_samples_alt;
     trt::GridView grids{};
     int dirgrid_cells = TRT_DIRGRID_CELLS, pointgrid_cells = TRT_POINTGRID_CELLS; // per side; 0 = no tables (sweep only)
     int dirgrid_slabs = TRT_DIRGRID_SLABS, pointgrid_shells = TRT_POINTGRID_SHELLS; // depth coordinate of the light tables (>= 1)
-    // the tables as LIST CELLS (trt_raygrid.h), which is what the kernel reads: one 64-bit word per cell, long lists in d_pool
-    DeviceBuffer<unsigned long long> d_dir_lists, d_point_lists, d_path_lists, d_pool;
-    DeviceBuffer<unsigned int> d_pool_used;    // [0] words taken by the scene's tables, [16] by the eye's (a cache line apart)
-    DeviceBuffer<trt_rayfamily> d_families;    // the 2NP families of the spheres, for the marking kernel
-    DeviceBuffer<double> d_sphere_fam;         // per sphere {mirror centre, |r|}: what the render kernel keeps in LDS
-    DeviceBuffer<double> d_patch_rec;          // per patch {t, rho, mirrored t, rho}: likewise
     int path_g_eye = TRT_PATHGRID_EYE, path_g_sph = TRT_PATHGRID_SPHERE; // 0 = no path tables (every path ray sweeps)
     int path_min_spheres = TRT_PATHGRID_MIN_SPHERES;                      // scenes with fewer spheres sweep
     int path_patches = TRT_PATHGRID_PATCHES;                              // m of the spheres' sub-families; -1: by the number of spheres
-    int path_built_for[4] = {-1, -1, -1, -2};
-    size_t pool_scene_words = 0, pool_eye_words = 0; // capacities of the two parts of d_pool
-    trt_cull_scene cull_scene{};                      // of the spheres the tables were built from
-    double eye_built[3] = {0.0, 0.0, 0.0}, ground_built[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    size_t list_pool_cap = 0;                                             // trt_set_list_pool_words: cap on the scene's part of the pool (0 = automatic)
+    double eye_built[3] = {0.0, 0.0, 0.0};
     bool eye_tables_valid = false;
-    std::vector<double> h_spheres, h_dir, h_point; // what the tables on the device were built from
-    int grids_built_for[4] = {-1, -1, -1, -1};
-    DeviceBuffer<uint32_t> d_sky;
     DeviceBuffer<double> d_ior; // refraction extension: per sphere, > 0 = index of refraction
     DeviceBuffer<unsigned char> d_rgb8; // trt_render_host_rgb8: the quantised frame before it crosses PCIe
     int ior_count = 0;          // 0 = off (the reference's path)
@@ -282,9 +317,9 @@ int upload_skybox(trt_context *ctx, const Skybox *sky)
         for (size_t i = 0; i < face; i++)
             dst[i] = (uint32_t)src[i].r | ((uint32_t)src[i].g << 8) | ((uint32_t)src[i].b << 16);
     }
-    HIP_TRY(ctx->d_sky.reserve(6 * face));
-    HIP_TRY(hipMemcpy(ctx->d_sky.ptr, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    ctx->scene.sky = ctx->d_sky.ptr;
+    HIP_TRY(ctx->T->d_sky.reserve(6 * face));
+    HIP_TRY(hipMemcpy(ctx->T->d_sky.ptr, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->scene.sky = ctx->T->d_sky.ptr;
     ctx->scene.sky_dim = dim;
     ctx->scene.sky_dim_f = (double)dim;
     for (int f = 0; f < 6; f++)
@@ -330,21 +365,26 @@ __global__ void build_pointgrid_kernel(const trt_pointgrid_cone *cones, int n, i
 
 // Mask words of a table -> list cells (trt_raygrid.h).  Lists longer than seven entries take words from the pool; when
 // the pool's part is exhausted the cell says TRT_LIST_NONE and its rays sweep.
-__device__ unsigned long long pack_cell(const unsigned long long *mask, int words, unsigned long long *pool, unsigned *pool_used, unsigned pool_limit,
-                                        int bits)
+// The counter has 64 bits: it keeps counting after the pool is exhausted (exhaustion is a normal mode: the cell then says "no
+// list" and its rays sweep), and a 32-bit one would wrap after 2^32 words' worth of requests and hand out words that earlier
+// cells already point to.
+__device__ unsigned long long pack_cell(const unsigned long long *mask, int words, unsigned long long *pool, unsigned long long *pool_used,
+                                        unsigned pool_limit, int bits)
 {
     const int count = trt_list_count(mask, words);
     const unsigned need = trt_list_pool_words(count, bits);
     if (need == 0)
         return trt_list_pack(mask, words, count, nullptr, 0u, bits);
-    const unsigned at = atomicAdd(pool_used, need);
-    if (count > 0xffff || at + need > pool_limit || at + need < at)
+    const unsigned long long at = atomicAdd(pool_used, (unsigned long long)need);
+    if (count > 0xffff || at + need > (unsigned long long)pool_limit)
         return (unsigned long long)TRT_LIST_NONE << 56;
-    return trt_list_pack(mask, words, count, pool, at, bits);
+    return trt_list_pack(mask, words, count, pool, (unsigned)at, bits);
 }
 
+__global__ void set_pool_counter_kernel(unsigned long long *counter, unsigned long long value) { *counter = value; }
+
 __global__ void pack_lists_kernel(const unsigned long long *masks, long cells, int words, unsigned long long *lists, unsigned long long *pool,
-                                  unsigned *pool_used, unsigned pool_limit, int bits)
+                                  unsigned long long *pool_used, unsigned pool_limit, int bits)
 {
     const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell < cells)
@@ -357,7 +397,7 @@ __global__ void pack_lists_kernel(const unsigned long long *masks, long cells, i
 // eye come as kernel arguments (they change with the camera), otherwise family blockIdx.y of `families`.
 __global__ __launch_bounds__(256) void build_family_lists_kernel(const double *spheres, int n, const trt_rayfamily *families, trt_rayfamily f0,
                                                                  trt_rayfamily f1, int by_value, int g, unsigned long long *lists,
-                                                                 unsigned long long *pool, unsigned *pool_used, unsigned pool_limit)
+                                                                 unsigned long long *pool, unsigned long long *pool_used, unsigned pool_limit)
 {
     __shared__ trt_pointgrid_cone cones[TRT_LIST_MAX_SPHERES];
     const trt_rayfamily F = by_value ? (blockIdx.y == 0 ? f0 : f1) : families[blockIdx.y];
@@ -380,14 +420,14 @@ __global__ __launch_bounds__(256) void build_family_lists_kernel(const double *s
 // host places each grid and prepares one small record per sphere and light, the device marks the cells.
 int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
 {
-    const int n = (int)(ctx->h_spheres.size() / 9), nd = (int)(ctx->h_dir.size() / 6), np = (int)(ctx->h_point.size() / 7);
+    const int n = (int)(ctx->T->h_spheres.size() / 9), nd = (int)(ctx->T->h_dir.size() / 6), np = (int)(ctx->T->h_point.size() / 7);
     const int gd = ctx->dirgrid_cells, gp = ctx->pointgrid_cells, sd = std::max(ctx->dirgrid_slabs, 1), sp = std::max(ctx->pointgrid_shells, 1);
     trt::GridView &g = ctx->grids;
     g.enabled = 0;
-    ctx->grids_built_for[0] = gd;
-    ctx->grids_built_for[1] = gp;
-    ctx->grids_built_for[2] = ctx->dirgrid_slabs;
-    ctx->grids_built_for[3] = ctx->pointgrid_shells;
+    ctx->T->grids_built_for[0] = gd;
+    ctx->T->grids_built_for[1] = gp;
+    ctx->T->grids_built_for[2] = ctx->dirgrid_slabs;
+    ctx->T->grids_built_for[3] = ctx->pointgrid_shells;
     if (gd < 8 || gp < 2 || nd + np == 0 || n > TRT_LIST_MAX_SPHERES_WIDE)
         return TRT_OK; // enabled = 0: the kernel sweeps
     const int bits = n > TRT_LIST_MAX_SPHERES ? 16 : 8; // entry width of the list cells
@@ -400,67 +440,75 @@ int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
     std::vector<trt_pointgrid_cone> cones(slots * np);
     for (int i = 0; i < nd; i++)
     {
-        const double *li = ctx->h_dir.data() + 6 * i;
+        const double *li = ctx->T->h_dir.data() + 6 * i;
         const double to_light[3] = {-li[0], -li[1], -li[2]}; // TRT.c:903; prepare normalises
         const double len2 = to_light[0] * to_light[0] + to_light[1] * to_light[1] + to_light[2] * to_light[2];
         if (!(len2 > 0.0) || !(len2 < 1e300))
             return TRT_OK; // a light without a direction: leave the tables off
-        trt_dirgrid_prepare(ctx->h_spheres.data(), n, &cs, to_light, gd, sd, &dg[i], discs.data() + slots * i);
+        trt_dirgrid_prepare(ctx->T->h_spheres.data(), n, &cs, to_light, gd, sd, &dg[i], discs.data() + slots * i);
     }
     for (int i = 0; i < np; i++)
-        trt_pointgrid_prepare(ctx->h_spheres.data(), n, &cs, ctx->h_point.data() + 7 * i, gp, sp, &pg[i], cones.data() + slots * i);
-    HIP_TRY(ctx->d_dir_masks.reserve(dir_stride * nd));
-    HIP_TRY(ctx->d_point_masks.reserve(point_stride * np));
-    HIP_TRY(ctx->d_dirgrids.reserve(nd));
-    HIP_TRY(ctx->d_pointgrids.reserve(np));
-    HIP_TRY(ctx->d_discs.reserve(discs.size()));
-    HIP_TRY(ctx->d_cones.reserve(cones.size()));
+        trt_pointgrid_prepare(ctx->T->h_spheres.data(), n, &cs, ctx->T->h_point.data() + 7 * i, gp, sp, &pg[i], cones.data() + slots * i);
+    HIP_TRY(ctx->T->d_dir_masks.reserve(dir_stride * nd));
+    HIP_TRY(ctx->T->d_point_masks.reserve(point_stride * np));
+    HIP_TRY(ctx->T->d_dirgrids.reserve(nd));
+    HIP_TRY(ctx->T->d_pointgrids.reserve(np));
+    HIP_TRY(ctx->T->d_discs.reserve(discs.size()));
+    HIP_TRY(ctx->T->d_cones.reserve(cones.size()));
     if (nd)
     {
-        HIP_TRY(hipMemcpy(ctx->d_dirgrids.ptr, dg.data(), dg.size() * sizeof(trt_dirgrid), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->d_discs.ptr, discs.data(), discs.size() * sizeof(trt_dirgrid_disc), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->T->d_dirgrids.ptr, dg.data(), dg.size() * sizeof(trt_dirgrid), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->T->d_discs.ptr, discs.data(), discs.size() * sizeof(trt_dirgrid_disc), hipMemcpyHostToDevice));
     }
     if (np)
     {
-        HIP_TRY(hipMemcpy(ctx->d_pointgrids.ptr, pg.data(), pg.size() * sizeof(trt_pointgrid), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->d_cones.ptr, cones.data(), cones.size() * sizeof(trt_pointgrid_cone), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->T->d_pointgrids.ptr, pg.data(), pg.size() * sizeof(trt_pointgrid), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->T->d_cones.ptr, cones.data(), cones.size() * sizeof(trt_pointgrid_cone), hipMemcpyHostToDevice));
     }
     const int block = 256;
     for (int i = 0; i < nd; i++)
         hipLaunchKernelGGL(build_dirgrid_kernel, dim3((unsigned)(((size_t)sd * gd * gd + block - 1) / block)), dim3(block), 0, ctx->stream,
-                           ctx->d_discs.ptr + slots * i, n, gd, sd, (int)words, ctx->d_dir_masks.ptr + dir_stride * i);
+                           ctx->T->d_discs.ptr + slots * i, n, gd, sd, (int)words, ctx->T->d_dir_masks.ptr + dir_stride * i);
     for (int i = 0; i < np; i++)
         hipLaunchKernelGGL(build_pointgrid_kernel, dim3((unsigned)((6 * (size_t)sp * gp * gp + block - 1) / block)), dim3(block), 0, ctx->stream,
-                           ctx->d_cones.ptr + slots * i, n, gp, sp, (int)words, ctx->d_point_masks.ptr + point_stride * i);
+                           ctx->T->d_cones.ptr + slots * i, n, gp, sp, (int)words, ctx->T->d_point_masks.ptr + point_stride * i);
     // the kernel reads list cells: pack every table (the mask words stay for trt_read_light_grid)
     const size_t dir_cells = (size_t)sd * gd * gd, point_cells = 6 * (size_t)sp * gp * gp;
-    HIP_TRY(ctx->d_dir_lists.reserve(dir_cells * nd));
-    HIP_TRY(ctx->d_point_lists.reserve(point_cells * np));
+    HIP_TRY(ctx->T->d_dir_lists.reserve(dir_cells * nd));
+    HIP_TRY(ctx->T->d_point_lists.reserve(point_cells * np));
     if (nd)
-        hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((dir_cells * nd + block - 1) / block)), dim3(block), 0, ctx->stream, ctx->d_dir_masks.ptr,
-                           (long)(dir_cells * nd), (int)words, ctx->d_dir_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words, bits);
+        hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((dir_cells * nd + block - 1) / block)), dim3(block), 0, ctx->stream, ctx->T->d_dir_masks.ptr,
+                           (long)(dir_cells * nd), (int)words, ctx->T->d_dir_lists.ptr, ctx->T->d_pool.ptr, ctx->T->d_pool_used.ptr, (unsigned)ctx->T->pool_scene_words, bits);
     if (np)
-        hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((point_cells * np + block - 1) / block)), dim3(block), 0, ctx->stream, ctx->d_point_masks.ptr,
-                           (long)(point_cells * np), (int)words, ctx->d_point_lists.ptr, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words, bits);
+        hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((point_cells * np + block - 1) / block)), dim3(block), 0, ctx->stream, ctx->T->d_point_masks.ptr,
+                           (long)(point_cells * np), (int)words, ctx->T->d_point_lists.ptr, ctx->T->d_pool.ptr, ctx->T->d_pool_used.ptr, (unsigned)ctx->T->pool_scene_words, bits);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // the caller may hand the context another stream before it renders
-    g.dir = ctx->d_dirgrids.ptr;
-    g.point = ctx->d_pointgrids.ptr;
-    g.dir_lists = ctx->d_dir_lists.ptr;
-    g.point_lists = ctx->d_point_lists.ptr;
+    g.dir = ctx->T->d_dirgrids.ptr;
+    g.point = ctx->T->d_pointgrids.ptr;
+    g.dir_lists = ctx->T->d_dir_lists.ptr;
+    g.point_lists = ctx->T->d_point_lists.ptr;
     g.dir_stride = (unsigned)dir_cells;
     g.point_stride = (unsigned)point_cells;
-    g.pool = ctx->d_pool.ptr;
+    g.pool = ctx->T->d_pool.ptr;
     g.enabled = 1;
     return TRT_OK;
 }
 
 // m of the spheres' sub-families (trt_raygrid.h) for a scene of n spheres
+// The automatic policy (path_patches = -1) also looks at what the tables would weigh: 6 m^2 tables per sphere and side -- 604 MB of
+// cells and a 302 MB pool at 256 spheres, 32 cells, m = 2 -- and steps m down (2 -> 1 -> 0) until cells and pool fit a budget
+// instead of failing in hipMalloc or on the 2^32-cell limit; an m asked for by number is taken as it is.
+constexpr unsigned long long kAutoPatchBudgetBytes = 4ull << 30;
 int patches_for(const trt_context *ctx, int n)
 {
     if (ctx->path_patches >= 0)
         return std::min(ctx->path_patches, TRT_PATCH_MAX_M);
-    return n >= TRT_PATCHES_FROM_SPHERES ? 2 : 0;
+    int m = n >= TRT_PATCHES_FROM_SPHERES ? 2 : 0;
+    const unsigned long long per_table = 6ull * (unsigned long long)ctx->path_g_sph * (unsigned long long)ctx->path_g_sph;
+    while (m > 0 && 2ull * (unsigned long long)n * (6ull * m * m) * per_table * 12ull > kAutoPatchBudgetBytes) // 8 B a cell + half a pool word
+        m--;
+    return m;
 }
 
 // Direction tables of the 2NP families of the spheres of the path rays (trt_raygrid.h: P patches per sphere and their mirror
@@ -468,17 +516,17 @@ int patches_for(const trt_context *ctx, int n)
 // device forms the cones and marks and packs the cells.
 int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const double *ground)
 {
-    const int n = (int)(ctx->h_spheres.size() / 9);
+    const int n = (int)(ctx->T->h_spheres.size() / 9);
     trt::GridView &g = ctx->grids;
     g.path_enabled = 0;
     g.patch_m = g.patch_count = 0;
     ctx->eye_tables_valid = false;
-    ctx->path_built_for[0] = ctx->path_g_eye;
-    ctx->path_built_for[1] = ctx->path_g_sph;
-    ctx->path_built_for[2] = ctx->path_min_spheres;
-    ctx->path_built_for[3] = ctx->path_patches;
-    ctx->cull_scene = cs;
-    memcpy(ctx->ground_built, ground, sizeof ctx->ground_built);
+    ctx->T->path_built_for[0] = ctx->path_g_eye;
+    ctx->T->path_built_for[1] = ctx->path_g_sph;
+    ctx->T->path_built_for[2] = ctx->path_min_spheres;
+    ctx->T->path_built_for[3] = ctx->path_patches;
+    ctx->T->cull_scene = cs;
+    memcpy(ctx->T->ground_built, ground, sizeof ctx->T->ground_built);
     const int ge = ctx->path_g_eye, gs = ctx->path_g_sph;
     if (ge < 2 || gs < 2 || n > TRT_LIST_MAX_SPHERES || n < ctx->path_min_spheres)
         return TRT_OK; // path_enabled = 0: every path ray sweeps
@@ -486,38 +534,39 @@ int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const double *
     trt_patchset_init(&patches, patches_for(ctx, n));
     const size_t P = (size_t)patches.count, families = 2 * (size_t)n * P;
     const size_t eye_cells = 6 * (size_t)ge * ge, sph_cells = 6 * (size_t)gs * gs;
-    if (2 * eye_cells + families * sph_cells >= 0xffffffffull)
+    const size_t eye_part = (size_t)kEyeSlots * 2 * eye_cells; // the eye's two tables of every slot first
+    if (eye_part + families * sph_cells >= 0xffffffffull)
         return fail(TRT_ERR_CAPACITY, "path tables of %zu families x %zu cells", families, sph_cells);
-    HIP_TRY(ctx->d_path_lists.reserve(2 * eye_cells + families * sph_cells)); // the eye's two tables first
-    HIP_TRY(ctx->d_families.reserve(std::max<size_t>(families, 1)));
-    HIP_TRY(ctx->d_sphere_fam.reserve(4 * (size_t)std::max(n, 1)));
-    HIP_TRY(ctx->d_patch_rec.reserve(P * TRT_PATCH_RECORD));
+    HIP_TRY(ctx->T->d_path_lists.reserve(eye_part + families * sph_cells));
+    HIP_TRY(ctx->T->d_families.reserve(std::max<size_t>(families, 1)));
+    HIP_TRY(ctx->T->d_sphere_fam.reserve(4 * (size_t)std::max(n, 1)));
+    HIP_TRY(ctx->T->d_patch_rec.reserve(P * TRT_PATCH_RECORD));
     std::vector<trt_rayfamily> fam(std::max<size_t>(families, 1));
     std::vector<double> rec(4 * (size_t)std::max(n, 1)), prec(P * TRT_PATCH_RECORD);
     trt_family_consts consts;
-    trt_sphere_families(ctx->h_spheres.data(), n, ground, &cs, &patches, fam.data(), rec.data(), &consts);
+    trt_sphere_families(ctx->T->h_spheres.data(), n, ground, &cs, &patches, fam.data(), rec.data(), &consts);
     trt_patch_records(&patches, ground, prec.data());
-    HIP_TRY(hipMemcpy(ctx->d_patch_rec.ptr, prec.data(), prec.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->T->d_patch_rec.ptr, prec.data(), prec.size() * sizeof(double), hipMemcpyHostToDevice));
     if (n)
     {
-        HIP_TRY(hipMemcpy(ctx->d_families.ptr, fam.data(), families * sizeof(trt_rayfamily), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->d_sphere_fam.ptr, rec.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->T->d_families.ptr, fam.data(), families * sizeof(trt_rayfamily), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->T->d_sphere_fam.ptr, rec.data(), 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
         for (size_t first = 0; first < families; first += 32768) // grid.y is limited to 65535
         {
             const unsigned batch = (unsigned)std::min<size_t>(32768, families - first);
             hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((sph_cells + 255) / 256), batch), dim3(256), 0, ctx->stream,
-                               (const double *)ctx->d_spheres.ptr, n, (const trt_rayfamily *)ctx->d_families.ptr + first, trt_rayfamily{}, trt_rayfamily{}, 0,
-                               gs, ctx->d_path_lists.ptr + 2 * eye_cells + first * sph_cells, ctx->d_pool.ptr, ctx->d_pool_used.ptr, (unsigned)ctx->pool_scene_words);
+                               (const double *)ctx->T->d_spheres.ptr, n, (const trt_rayfamily *)ctx->T->d_families.ptr + first, trt_rayfamily{}, trt_rayfamily{}, 0,
+                               gs, ctx->T->d_path_lists.ptr + eye_part + first * sph_cells, ctx->T->d_pool.ptr, ctx->T->d_pool_used.ptr, (unsigned)ctx->T->pool_scene_words);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    g.path_lists = ctx->d_path_lists.ptr;
-    g.eye_at = 0;
-    g.sph_at = (unsigned)(2 * eye_cells);
-    g.pool = ctx->d_pool.ptr;
-    g.sphere_fam = ctx->d_sphere_fam.ptr;
-    g.patch_rec = ctx->d_patch_rec.ptr;
+    g.path_lists = ctx->T->d_path_lists.ptr;
+    g.eye_at = (unsigned)((size_t)ctx->eye_slot * 2 * eye_cells);
+    g.sph_at = (unsigned)eye_part;
+    g.pool = ctx->T->d_pool.ptr;
+    g.sphere_fam = ctx->T->d_sphere_fam.ptr;
+    g.patch_rec = ctx->T->d_patch_rec.ptr;
     g.patch_m = patches.m;
     g.patch_count = patches.count;
     g.rg2_sph = consts.rg * consts.rg;
@@ -532,28 +581,32 @@ int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const double *
 // the eye's, which are rebuilt per camera), then the light tables, then the sphere families.
 int build_tables(trt_context *ctx, const trt_cull_scene &cs, const double *ground)
 {
-    const size_t n = ctx->h_spheres.size() / 9, nd = ctx->h_dir.size() / 6, np = ctx->h_point.size() / 7;
+    const size_t n = ctx->T->h_spheres.size() / 9, nd = ctx->T->h_dir.size() / 6, np = ctx->T->h_point.size() / 7;
     const size_t gd = (size_t)ctx->dirgrid_cells, gp = (size_t)ctx->pointgrid_cells, ge = (size_t)ctx->path_g_eye, gs = (size_t)ctx->path_g_sph;
     const size_t sd = (size_t)std::max(ctx->dirgrid_slabs, 1), sp = (size_t)std::max(ctx->pointgrid_shells, 1);
     // one pool word per cell; the many small tables of sub-families (their lists are short: that is what they are for) get
     // half a word per cell -- a list that finds no room leaves its cell TRT_LIST_NONE and its rays sweep
     const int m = patches_for(ctx, (int)n);
     const size_t sphere_cells = 2 * n * (m ? 6 * (size_t)m * m : 1) * 6 * gs * gs;
-    ctx->pool_scene_words = std::max<size_t>(1024, nd * sd * gd * gd + np * 6 * sp * gp * gp + (m ? sphere_cells / 2 : sphere_cells));
-    ctx->pool_eye_words = std::max<size_t>(1024, 2 * 6 * ge * ge);
-    if (ctx->pool_scene_words + ctx->pool_eye_words >= 0xffffffffull)
+    ctx->T->pool_scene_words = std::max<size_t>(1024, nd * sd * gd * gd + np * 6 * sp * gp * gp + (m ? sphere_cells / 2 : sphere_cells));
+    ctx->T->pool_eye_words = std::max<size_t>(1024, 2 * 6 * ge * ge);
+    if (ctx->T->pool_scene_words + kEyeSlots * ctx->T->pool_eye_words >= 0xffffffffull)
         return fail(TRT_ERR_CAPACITY, "candidate tables too large");
     if (n > TRT_LIST_MAX_SPHERES) // no sphere families; 16-bit entries: long lists take twice the words
-        ctx->pool_scene_words = std::max<size_t>(1024, 2 * (nd * sd * gd * gd + np * 6 * sp * gp * gp));
+        ctx->T->pool_scene_words = std::max<size_t>(1024, 2 * (nd * sd * gd * gd + np * 6 * sp * gp * gp));
+    if (ctx->list_pool_cap) // trt_set_list_pool_words (tests: the pool's exhaustion)
+        ctx->T->pool_scene_words = std::min(ctx->T->pool_scene_words, std::max<size_t>(ctx->list_pool_cap, 1));
     ctx->grids = trt::GridView{};
     ctx->grids.list_bits = 8;
-    HIP_TRY(ctx->d_pool.reserve(ctx->pool_scene_words + ctx->pool_eye_words));
-    HIP_TRY(ctx->d_pool_used.reserve(32));
-    HIP_TRY(hipMemsetAsync(ctx->d_pool_used.ptr, 0, 32 * sizeof(unsigned), ctx->stream));
+    HIP_TRY(ctx->T->d_pool.reserve(ctx->T->pool_scene_words + kEyeSlots * ctx->T->pool_eye_words));
+    HIP_TRY(ctx->T->d_pool_used.reserve(16 * (1 + kEyeSlots)));
+    HIP_TRY(hipMemsetAsync(ctx->T->d_pool_used.ptr, 0, 16 * (1 + kEyeSlots) * sizeof(unsigned long long), ctx->stream));
+    const double t0 = host_seconds();
     int rc = build_light_grids(ctx, cs);
-    if (rc)
-        return rc;
-    return build_path_tables(ctx, cs, ground);
+    if (!rc)
+        rc = build_path_tables(ctx, cs, ground);
+    ctx->T->build_seconds = host_seconds() - t0;
+    return rc;
 }
 
 // The two families of the eye (trt_raygrid.h): rebuilt on `stream` whenever the eye (or the scene) changed since they were built.
@@ -565,13 +618,16 @@ int ensure_eye_tables(trt_context *ctx, const Camera *camera, hipStream_t stream
     const double eye[3] = {camera->frame.origin.x, camera->frame.origin.y, camera->frame.origin.z};
     if (ctx->eye_tables_valid && !memcmp(eye, ctx->eye_built, sizeof eye))
         return TRT_OK;
-    trt_eye_families(eye, ctx->ground_built, &ctx->cull_scene, g.eye);
-    const int n = (int)(ctx->h_spheres.size() / 9), ge = g.g_eye;
+    trt_eye_families(eye, ctx->T->ground_built, &ctx->T->cull_scene, g.eye);
+    const int n = (int)(ctx->T->h_spheres.size() / 9), ge = g.g_eye;
     const size_t eye_cells = 6 * (size_t)ge * ge;
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->d_pool_used.ptr + 16), (int)ctx->pool_scene_words, 1, stream));
-    hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((eye_cells + 255) / 256), 2u), dim3(256), 0, stream, (const double *)ctx->d_spheres.ptr, n,
-                       (const trt_rayfamily *)nullptr, g.eye[0], g.eye[1], 1, ge, ctx->d_path_lists.ptr + g.eye_at, ctx->d_pool.ptr, ctx->d_pool_used.ptr + 16,
-                       (unsigned)(ctx->pool_scene_words + ctx->pool_eye_words));
+    // this context's part of the pool: behind the scene's part and the parts of the slots before it
+    const size_t pool_from = ctx->T->pool_scene_words + (size_t)ctx->eye_slot * ctx->T->pool_eye_words;
+    unsigned long long *const counter = ctx->T->d_pool_used.ptr + 16 * (1 + ctx->eye_slot);
+    hipLaunchKernelGGL(set_pool_counter_kernel, dim3(1), dim3(1), 0, stream, counter, (unsigned long long)pool_from);
+    hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((eye_cells + 255) / 256), 2u), dim3(256), 0, stream, (const double *)ctx->T->d_spheres.ptr, n,
+                       (const trt_rayfamily *)nullptr, g.eye[0], g.eye[1], 1, ge, ctx->T->d_path_lists.ptr + g.eye_at, ctx->T->d_pool.ptr, counter,
+                       (unsigned)(pool_from + ctx->T->pool_eye_words));
     HIP_TRY(hipGetLastError());
     memcpy(ctx->eye_built, eye, sizeof eye);
     ctx->eye_tables_valid = true;
@@ -611,25 +667,25 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
         return fail(TRT_ERR_ARGUMENT, "negative primitive count");
     if ((n && !scene->spheres) || (nd && !scene->directional_lights) || (np && !scene->point_lights))
         return fail(TRT_ERR_ARGUMENT, "NULL primitive array with a non-zero count");
-    HIP_TRY(ctx->d_spheres.reserve((size_t)n * 9));
-    HIP_TRY(ctx->d_dir.reserve((size_t)nd * 6));
-    HIP_TRY(ctx->d_point.reserve((size_t)np * 7));
+    HIP_TRY(ctx->T->d_spheres.reserve((size_t)n * 9));
+    HIP_TRY(ctx->T->d_dir.reserve((size_t)nd * 6));
+    HIP_TRY(ctx->T->d_point.reserve((size_t)np * 7));
     if (n)
-        HIP_TRY(hipMemcpy(ctx->d_spheres.ptr, scene->spheres, (size_t)n * sizeof(Sphere), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->T->d_spheres.ptr, scene->spheres, (size_t)n * sizeof(Sphere), hipMemcpyHostToDevice));
     if (nd)
-        HIP_TRY(hipMemcpy(ctx->d_dir.ptr, scene->directional_lights, (size_t)nd * sizeof(DirectionalLight), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->T->d_dir.ptr, scene->directional_lights, (size_t)nd * sizeof(DirectionalLight), hipMemcpyHostToDevice));
     if (np)
-        HIP_TRY(hipMemcpy(ctx->d_point.ptr, scene->point_lights, (size_t)np * sizeof(PointLight), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->T->d_point.ptr, scene->point_lights, (size_t)np * sizeof(PointLight), hipMemcpyHostToDevice));
 
     // FP32 culling table {Cx,Cy,Cz,kk} of trt_filter.h (filter only, never decides a result)
     const int padded = trt_cull_padded(n, trt::kCullGroup);
     std::vector<float> cull((size_t)padded * 4);
     trt_cull_scene cs;
     trt_cull_build((const double *)scene->spheres, n, trt::kCullGroup, cull.data(), &cs);
-    HIP_TRY(ctx->d_cull.reserve(cull.size()));
+    HIP_TRY(ctx->T->d_cull.reserve(cull.size()));
     if (padded)
-        HIP_TRY(hipMemcpy(ctx->d_cull.ptr, cull.data(), cull.size() * sizeof(float), hipMemcpyHostToDevice));
-    ctx->cull.table = ctx->d_cull.ptr;
+        HIP_TRY(hipMemcpy(ctx->T->d_cull.ptr, cull.data(), cull.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->cull.table = ctx->T->d_cull.ptr;
     ctx->cull.padded = padded;
     ctx->cull.c0x = cs.c0[0];
     ctx->cull.c0y = cs.c0[1];
@@ -639,32 +695,32 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
 
     // the light-space tables only change with the spheres and the lights (a render loop usually moves the camera only)
     const double *hs = (const double *)scene->spheres, *hd = (const double *)scene->directional_lights, *hp = (const double *)scene->point_lights;
-    const bool same = ctx->h_spheres.size() == (size_t)n * 9 && ctx->h_dir.size() == (size_t)nd * 6 && ctx->h_point.size() == (size_t)np * 7 &&
-                      (!n || !memcmp(ctx->h_spheres.data(), hs, (size_t)n * sizeof(Sphere))) &&
-                      (!nd || !memcmp(ctx->h_dir.data(), hd, (size_t)nd * sizeof(DirectionalLight))) &&
-                      (!np || !memcmp(ctx->h_point.data(), hp, (size_t)np * sizeof(PointLight))) &&
-                      ctx->grids_built_for[0] == ctx->dirgrid_cells && ctx->grids_built_for[1] == ctx->pointgrid_cells &&
-                      ctx->grids_built_for[2] == ctx->dirgrid_slabs && ctx->grids_built_for[3] == ctx->pointgrid_shells &&
-                      ctx->path_built_for[0] == ctx->path_g_eye && ctx->path_built_for[1] == ctx->path_g_sph &&
-                      ctx->path_built_for[2] == ctx->path_min_spheres && ctx->path_built_for[3] == ctx->path_patches &&
-                      !memcmp(ctx->ground_built, &scene->ground, sizeof ctx->ground_built);
+    const bool same = ctx->T->h_spheres.size() == (size_t)n * 9 && ctx->T->h_dir.size() == (size_t)nd * 6 && ctx->T->h_point.size() == (size_t)np * 7 &&
+                      (!n || !memcmp(ctx->T->h_spheres.data(), hs, (size_t)n * sizeof(Sphere))) &&
+                      (!nd || !memcmp(ctx->T->h_dir.data(), hd, (size_t)nd * sizeof(DirectionalLight))) &&
+                      (!np || !memcmp(ctx->T->h_point.data(), hp, (size_t)np * sizeof(PointLight))) &&
+                      ctx->T->grids_built_for[0] == ctx->dirgrid_cells && ctx->T->grids_built_for[1] == ctx->pointgrid_cells &&
+                      ctx->T->grids_built_for[2] == ctx->dirgrid_slabs && ctx->T->grids_built_for[3] == ctx->pointgrid_shells &&
+                      ctx->T->path_built_for[0] == ctx->path_g_eye && ctx->T->path_built_for[1] == ctx->path_g_sph &&
+                      ctx->T->path_built_for[2] == ctx->path_min_spheres && ctx->T->path_built_for[3] == ctx->path_patches &&
+                      !memcmp(ctx->T->ground_built, &scene->ground, sizeof ctx->T->ground_built);
     if (!same)
     {
-        ctx->h_spheres.assign(hs, hs + (size_t)n * 9);
-        ctx->h_dir.assign(hd, hd + (size_t)nd * 6);
-        ctx->h_point.assign(hp, hp + (size_t)np * 7);
+        ctx->T->h_spheres.assign(hs, hs + (size_t)n * 9);
+        ctx->T->h_dir.assign(hd, hd + (size_t)nd * 6);
+        ctx->T->h_point.assign(hp, hp + (size_t)np * 7);
         const int rc = build_tables(ctx, cs, (const double *)&scene->ground);
         if (rc)
         {
-            ctx->grids_built_for[0] = ctx->grids_built_for[1] = ctx->grids_built_for[2] = ctx->grids_built_for[3] = -1;
+            ctx->T->grids_built_for[0] = ctx->T->grids_built_for[1] = ctx->T->grids_built_for[2] = ctx->T->grids_built_for[3] = -1;
             return rc;
         }
     }
 
     trt::SceneView &v = ctx->scene;
-    v.spheres = ctx->d_spheres.ptr;
-    v.dir_lights = ctx->d_dir.ptr;
-    v.point_lights = ctx->d_point.ptr;
+    v.spheres = ctx->T->d_spheres.ptr;
+    v.dir_lights = ctx->T->d_dir.ptr;
+    v.point_lights = ctx->T->d_point.ptr;
     v.num_spheres = n;
     v.num_dir = nd;
     v.num_point = np;
@@ -775,6 +831,9 @@ static int init_context(trt_context *ctx)
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     ctx->compute_units = prop.multiProcessorCount;
     ctx->lds_limit = (int)prop.sharedMemPerBlock;
+    ctx->T = std::make_shared<SceneTables>();
+    ctx->T->device = device;
+    ctx->T->eye_slots_taken = 1u;
     if (const char *e = getenv("TRT_LIGHTGRID"))
     {
         int gd = 0, gp = 0, sd = TRT_DIRGRID_SLABS, sp = TRT_POINTGRID_SHELLS;
@@ -857,31 +916,15 @@ extern "C" int trt_destroy(trt_context *ctx)
         (void)hipStreamDestroy(ctx->alt_stream);
     if (ctx->ev_fork)
         (void)hipEventDestroy(ctx->ev_fork);
-    ctx->d_spheres.release();
-    ctx->d_dir.release();
-    ctx->d_point.release();
+    if (ctx->T)
+        ctx->T->eye_slots_taken &= ~(1u << ctx->eye_slot);
+    ctx->T.reset(); // the tables go with their last context
     ctx->d_jitter.release();
     ctx->d_axes.release();
     ctx->d_samples.release();
     ctx->d_samples_alt.release();
     ctx->d_fb.release();
     ctx->d_rgb8.release();
-    ctx->d_cull.release();
-    ctx->d_dir_lists.release();
-    ctx->d_point_lists.release();
-    ctx->d_path_lists.release();
-    ctx->d_patch_rec.release();
-    ctx->d_pool.release();
-    ctx->d_pool_used.release();
-    ctx->d_families.release();
-    ctx->d_sphere_fam.release();
-    ctx->d_dir_masks.release();
-    ctx->d_point_masks.release();
-    ctx->d_dirgrids.release();
-    ctx->d_pointgrids.release();
-    ctx->d_discs.release();
-    ctx->d_cones.release();
-    ctx->d_sky.release();
     ctx->d_ior.release();
     ctx->d_counters.release();
     ctx->d_queue.release();
@@ -939,6 +982,104 @@ extern "C" int trt_get_stream(trt_context *ctx, void **hip_stream)
     return TRT_OK;
 }
 
+// a context that shares its tables gets fresh, empty ones of its own (slot 0)
+static void detach_tables(trt_context *ctx)
+{
+    if (ctx->T.use_count() <= 1)
+        return;
+    ctx->T->eye_slots_taken &= ~(1u << ctx->eye_slot);
+    ctx->T = std::make_shared<SceneTables>();
+    ctx->T->device = ctx->device;
+    ctx->T->eye_slots_taken = 1u;
+    ctx->eye_slot = 0;
+    ctx->eye_tables_valid = false;
+    ctx->grids = trt::GridView{};
+    ctx->sky_dim = -1;
+}
+
+static int refuse_if_shared(const trt_context *ctx, const char *what)
+{
+    if (ctx->T.use_count() > 1)
+        return fail(TRT_ERR_ARGUMENT, "%s: this context's scene tables are shared with %ld other context(s) (trt_share_scene); "
+                                      "change them before sharing, or give the context a scene of its own (trt_set_scene)", what, ctx->T.use_count() - 1);
+    return TRT_OK;
+}
+
+// dst renders the scene of src from src's tables (same device): nothing is uploaded or built again; only what depends on the
+// camera -- the eye's two tables, in a slot of their own -- and the per-frame buffers stay dst's.  Up to kEyeSlots contexts per scene.
+extern "C" int trt_share_scene(trt_context *dst, trt_context *src)
+{
+    if (!dst || !src || dst == src)
+        return fail(TRT_ERR_ARGUMENT, "bad argument");
+    if (!src->have_scene)
+        return fail(TRT_ERR_NO_SCENE, "the source context has no scene");
+    if (dst->device != src->device)
+        return fail(TRT_ERR_ARGUMENT, "contexts of different devices (%d, %d) cannot share tables", dst->device, src->device);
+    HIP_TRY(hipSetDevice(dst->device));
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    if (dst->T == src->T)
+        return TRT_OK;
+    int slot = -1;
+    for (int k = 0; k < kEyeSlots && slot < 0; k++)
+        if (!(src->T->eye_slots_taken & (1u << k)))
+            slot = k;
+    if (slot < 0)
+        return fail(TRT_ERR_CAPACITY, "%d contexts share these tables already", kEyeSlots);
+    dst->T->eye_slots_taken &= ~(1u << dst->eye_slot);
+    dst->T = src->T;
+    dst->T->eye_slots_taken |= 1u << slot;
+    dst->eye_slot = slot;
+    dst->scene = src->scene;
+    dst->cull = src->cull;
+    dst->grids = src->grids;
+    dst->grids.eye_at = (unsigned)((size_t)slot * 2 * 6 * (size_t)src->grids.g_eye * (size_t)src->grids.g_eye);
+    dst->eye_tables_valid = false;
+    // the settings the tables were built with travel along (a later trt_set_scene on dst then builds alike)
+    dst->dirgrid_cells = src->dirgrid_cells, dst->pointgrid_cells = src->pointgrid_cells;
+    dst->dirgrid_slabs = src->dirgrid_slabs, dst->pointgrid_shells = src->pointgrid_shells;
+    dst->path_g_eye = src->path_g_eye, dst->path_g_sph = src->path_g_sph, dst->path_min_spheres = src->path_min_spheres;
+    dst->path_patches = src->path_patches, dst->list_pool_cap = src->list_pool_cap;
+    memcpy(dst->sky_faces, src->sky_faces, sizeof dst->sky_faces);
+    dst->sky_dim = src->sky_dim;
+    dst->sky_stamp = src->sky_stamp;
+    dst->ior_count = 0;
+    dst->have_scene = true;
+    dst->occupancy_for_lds = (size_t)-1;
+    return refresh_occupancy(dst);
+}
+
+// {bytes of device memory held by the scene's tables and primitives, contexts sharing them, host seconds of the last table build}
+extern "C" int trt_scene_info(trt_context *ctx, unsigned long long *table_bytes, int *sharers, double *build_seconds)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    const SceneTables &t = *ctx->T;
+    if (table_bytes)
+        *table_bytes = t.d_spheres.capacity * 8 + t.d_dir.capacity * 8 + t.d_point.capacity * 8 + t.d_cull.capacity * 4 + t.d_dir_masks.capacity * 8 +
+                       t.d_point_masks.capacity * 8 + t.d_dirgrids.capacity * sizeof(trt_dirgrid) + t.d_pointgrids.capacity * sizeof(trt_pointgrid) +
+                       t.d_discs.capacity * sizeof(trt_dirgrid_disc) + t.d_cones.capacity * sizeof(trt_pointgrid_cone) + t.d_dir_lists.capacity * 8 +
+                       t.d_point_lists.capacity * 8 + t.d_path_lists.capacity * 8 + t.d_pool.capacity * 8 + t.d_pool_used.capacity * 8 +
+                       t.d_families.capacity * sizeof(trt_rayfamily) + t.d_sphere_fam.capacity * 8 + t.d_patch_rec.capacity * 8 + t.d_sky.capacity * 4;
+    if (sharers)
+        *sharers = (int)ctx->T.use_count();
+    if (build_seconds)
+        *build_seconds = t.build_seconds;
+    return TRT_OK;
+}
+
+extern "C" int trt_set_list_pool_words(trt_context *ctx, size_t words)
+{
+    if (!ctx)
+        return fail(TRT_ERR_ARGUMENT, "ctx is NULL");
+    const int rc = refuse_if_shared(ctx, "trt_set_list_pool_words");
+    if (rc)
+        return rc;
+    ctx->list_pool_cap = words;
+    ctx->T->grids_built_for[0] = -1; // the next trt_set_scene / table setter builds again
+    return TRT_OK;
+}
+
 extern "C" int trt_set_scene(trt_context *ctx, const Scene *scene)
 {
     if (!ctx || !scene)
@@ -946,6 +1087,7 @@ extern "C" int trt_set_scene(trt_context *ctx, const Scene *scene)
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->have_scene = false;
+    detach_tables(ctx); // tables shared with other contexts (trt_share_scene) stay theirs: this context builds its own
     int rc = upload_primitives(ctx, scene);
     if (rc)
         return rc;
@@ -1042,16 +1184,18 @@ extern "C" int trt_set_light_grids(trt_context *ctx, int directional_cells, int 
 {
     if (!ctx || directional_cells < 0 || point_cells < 0 || directional_cells > 2048 || point_cells > 1024)
         return fail(TRT_ERR_ARGUMENT, "light grids %d, %d", directional_cells, point_cells);
+    if (const int shared = refuse_if_shared(ctx, "trt_set_light_grids"))
+        return shared;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still read the old tables
     ctx->dirgrid_cells = directional_cells;
     ctx->pointgrid_cells = point_cells;
     if (!ctx->have_scene)
         return TRT_OK;
-    const int n = (int)(ctx->h_spheres.size() / 9);
+    const int n = (int)(ctx->T->h_spheres.size() / 9);
     std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
     trt_cull_scene cs;
-    trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
+    trt_cull_build(ctx->T->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
     const int rc = build_tables(ctx, cs, ctx->scene.ground);
     return rc ? rc : refresh_occupancy(ctx);
 }
@@ -1060,6 +1204,8 @@ extern "C" int trt_set_light_slabs(trt_context *ctx, int directional_slabs, int 
 {
     if (!ctx || directional_slabs < 1 || point_shells < 1 || directional_slabs > 64 || point_shells > 64)
         return fail(TRT_ERR_ARGUMENT, "light slabs %d, %d", directional_slabs, point_shells);
+    if (const int shared = refuse_if_shared(ctx, "trt_set_light_slabs"))
+        return shared;
     ctx->dirgrid_slabs = directional_slabs;
     ctx->pointgrid_shells = point_shells;
     return trt_set_light_grids(ctx, ctx->dirgrid_cells, ctx->pointgrid_cells);
@@ -1069,16 +1215,18 @@ extern "C" int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_ce
 {
     if (!ctx || eye_cells < 0 || sphere_cells < 0 || eye_cells > 1024 || sphere_cells > 256)
         return fail(TRT_ERR_ARGUMENT, "path grids %d, %d", eye_cells, sphere_cells);
+    if (const int shared = refuse_if_shared(ctx, "trt_set_path_grids"))
+        return shared;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still read the old tables
     ctx->path_g_eye = eye_cells;
     ctx->path_g_sph = sphere_cells;
     if (!ctx->have_scene)
         return TRT_OK;
-    const int n = (int)(ctx->h_spheres.size() / 9);
+    const int n = (int)(ctx->T->h_spheres.size() / 9);
     std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
     trt_cull_scene cs;
-    trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
+    trt_cull_build(ctx->T->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
     const int rc = build_tables(ctx, cs, ctx->scene.ground);
     return rc ? rc : refresh_occupancy(ctx);
 }
@@ -1087,15 +1235,17 @@ extern "C" int trt_set_path_patches(trt_context *ctx, int m)
 {
     if (!ctx || m < -1 || m > TRT_PATCH_MAX_M)
         return fail(TRT_ERR_ARGUMENT, "patches %d", m);
+    if (const int shared = refuse_if_shared(ctx, "trt_set_path_patches"))
+        return shared;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // a frame in flight may still read the old tables
     ctx->path_patches = m;
     if (!ctx->have_scene)
         return TRT_OK;
-    const int n = (int)(ctx->h_spheres.size() / 9);
+    const int n = (int)(ctx->T->h_spheres.size() / 9);
     std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
     trt_cull_scene cs;
-    trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
+    trt_cull_build(ctx->T->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
     const int rc = build_tables(ctx, cs, ctx->scene.ground);
     return rc ? rc : refresh_occupancy(ctx);
 }
@@ -1117,7 +1267,7 @@ extern "C" int trt_path_family_code(trt_context *ctx, int kind, int sphere, cons
         return -1;
     if (kind < 2)
         return kind;
-    const int n = (int)(ctx->h_spheres.size() / 9);
+    const int n = (int)(ctx->T->h_spheres.size() / 9);
     if (sphere < 0 || sphere >= n)
         return -1;
     if (kind == 2)
@@ -1126,7 +1276,7 @@ extern "C" int trt_path_family_code(trt_context *ctx, int kind, int sphere, cons
         return -1;
     if (!ctx->grids.patch_m)
         return 2 + n + sphere; // one family per sphere
-    const double *c = ctx->h_spheres.data() + 9 * (size_t)sphere;
+    const double *c = ctx->T->h_spheres.data() + 9 * (size_t)sphere;
     const int k = trt_patch_of(ctx->grids.patch_m, parent_origin[0] - c[0], parent_origin[1] - c[1], parent_origin[2] - c[2]);
     return 2 + n + ((sphere << TRT_PATCH_SHIFT) | k);
 }
@@ -1135,15 +1285,17 @@ extern "C" int trt_set_path_grids_min_spheres(trt_context *ctx, int min_spheres)
 {
     if (!ctx || min_spheres < 0)
         return fail(TRT_ERR_ARGUMENT, "min_spheres %d", min_spheres);
+    if (const int shared = refuse_if_shared(ctx, "trt_set_path_grids_min_spheres"))
+        return shared;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->path_min_spheres = min_spheres;
     if (!ctx->have_scene)
         return TRT_OK;
-    const int n = (int)(ctx->h_spheres.size() / 9);
+    const int n = (int)(ctx->T->h_spheres.size() / 9);
     std::vector<float> table((size_t)trt_cull_padded(n, trt::kCullGroup) * 4 + 4);
     trt_cull_scene cs;
-    trt_cull_build(ctx->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
+    trt_cull_build(ctx->T->h_spheres.data(), n, trt::kCullGroup, table.data(), &cs);
     const int rc = build_tables(ctx, cs, ctx->scene.ground);
     return rc ? rc : refresh_occupancy(ctx);
 }
@@ -1161,22 +1313,23 @@ extern "C" long trt_read_path_tables(trt_context *ctx, const Camera *camera, uns
         return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const trt::GridView &g = ctx->grids;
-    const int n = (int)(ctx->h_spheres.size() / 9);
-    unsigned used[32] = {0};
-    HIP_TRY(hipMemcpy(used, ctx->d_pool_used.ptr, sizeof used, hipMemcpyDeviceToHost));
+    const int n = (int)(ctx->T->h_spheres.size() / 9);
+    unsigned long long used[16 * (1 + kEyeSlots)] = {0};
+    HIP_TRY(hipMemcpy(used, ctx->T->d_pool_used.ptr, sizeof used, hipMemcpyDeviceToHost));
     const size_t eye_total = 2 * 6 * (size_t)g.g_eye * g.g_eye, sph_total = 2 * (size_t)n * (size_t)g.patch_count * 6 * (size_t)g.g_sph * g.g_sph;
     const size_t total = g.path_enabled ? eye_total + sph_total : 0;
-    const size_t pool_words = ctx->pool_scene_words + ctx->pool_eye_words;
+    const size_t pool_words = ctx->T->pool_scene_words + kEyeSlots * ctx->T->pool_eye_words; // the whole pool: the cells' offsets are into it
+    const size_t eye_from = ctx->T->pool_scene_words + (size_t)ctx->eye_slot * ctx->T->pool_eye_words;
     info[0] = g.path_enabled, info[1] = g.g_eye, info[2] = g.g_sph, info[3] = n, info[4] = (long)total;
-    info[5] = (long)used[0], info[6] = (long)used[16] - (long)ctx->pool_scene_words, info[7] = (long)pool_words;
+    info[5] = (long)std::min<unsigned long long>(used[0], 1ull << 62), info[6] = (long)used[16 * (1 + ctx->eye_slot)] - (long)eye_from, info[7] = (long)pool_words;
     if (!g.path_enabled)
         return 0;
     if (capacity_cells < total || capacity_pool < pool_words)
         return fail(TRT_ERR_CAPACITY, "tables have %zu cells and %zu pool words", total, pool_words);
-    HIP_TRY(hipMemcpy(cells, ctx->d_path_lists.ptr + g.eye_at, eye_total * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cells, ctx->T->d_path_lists.ptr + g.eye_at, eye_total * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (sph_total)
-        HIP_TRY(hipMemcpy(cells + eye_total, ctx->d_path_lists.ptr + g.sph_at, sph_total * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pool, ctx->d_pool.ptr, pool_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(cells + eye_total, ctx->T->d_path_lists.ptr + g.sph_at, sph_total * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pool, ctx->T->d_pool.ptr, pool_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return (long)total;
 }
 
@@ -1197,7 +1350,7 @@ extern "C" long trt_read_light_grid(trt_context *ctx, int point_light, int index
         return fail(TRT_ERR_CAPACITY, "table has %zu words, buffer %zu", stride, capacity_words);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(masks, (point_light ? ctx->d_point_masks.ptr : ctx->d_dir_masks.ptr) + stride * (size_t)index, stride * sizeof(unsigned long long),
+    HIP_TRY(hipMemcpy(masks, (point_light ? ctx->T->d_point_masks.ptr : ctx->T->d_dir_masks.ptr) + stride * (size_t)index, stride * sizeof(unsigned long long),
                       hipMemcpyDeviceToHost));
     return (long)stride;
 }
@@ -1719,7 +1872,23 @@ extern "C" int trt_probe_rays_production(trt_context *ctx, const Camera *camera,
     double *dr = buf.ptr, *dp = dr + 6 * n, *dn = dp + 3 * n, *dm = dn + 3 * n, *dl = dm + 5 * n;
     HIP_TRY(hipMemcpy(dr, rays, n * sizeof(Ray), hipMemcpyHostToDevice));
     if (families)
-        HIP_TRY(hipMemcpy(dobj.ptr + n, families, n * sizeof(int), hipMemcpyHostToDevice));
+    { // only codes the kernel can decode reach it: 0, 1, 2 + i, and 2 + N + i (one family per sphere) or 2 + N + (i << 7 | k) with
+      // k < patches (a patch number beyond the tables would index past the LDS image and the lists); anything else: no family
+        const int ns = ctx->scene.num_spheres, pm = ctx->grids.path_enabled ? ctx->grids.patch_m : 0, pc = ctx->grids.path_enabled ? ctx->grids.patch_count : 0;
+        std::vector<int> codes(families, families + n);
+        for (int &c : codes)
+        {
+            bool ok = c == 0 || c == 1 || (c >= 2 && c < 2 + ns);
+            if (!ok && c >= 2 + ns)
+            {
+                const int rest = c - 2 - ns;
+                ok = pm ? ((rest >> TRT_PATCH_SHIFT) < ns && (rest & ((1 << TRT_PATCH_SHIFT) - 1)) < pc) : rest < ns;
+            }
+            if (!ok)
+                c = -1;
+        }
+        HIP_TRY(hipMemcpy(dobj.ptr + n, codes.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    }
     trt::FrameView f{};
     memcpy(f.cam, camera, sizeof(Camera));
     f.jitter = ctx->d_jitter.ptr; // spp = 0: nothing is read through it

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -66,8 +67,13 @@ struct Rccl
 
 // Bound once, by whichever thread comes first (one rank may be one THREAD per GPU: trt_hip.h); the struct is published only
 // after every symbol is bound.  TRT_RCCL_LIB names another library with the same eight entry points (the tests' stand-in
-// that lets several ranks share one GPU, tests/rccl_stub.cpp); the product never sets it.
+// that lets several ranks share one GPU, tests/rccl_stub.cpp).  It is a TEST HOOK and is honoured only by a process that has
+// asked for it BEFORE the first use of RCCL (trt_dist_allow_rccl_override(1)): a product process ignores the variable and binds
+// RCCL itself.  trt_dist_rccl_library() says which library was bound.
 Rccl g_rccl; // written inside the call_once below, read-only afterwards
+std::atomic<int> g_override_allowed{0};
+std::atomic<int> g_bind_started{0};
+char g_bound_name[512] = ""; // written inside the call_once, read-only afterwards
 
 Rccl *rccl()
 {
@@ -75,12 +81,17 @@ Rccl *rccl()
     static Rccl *published = nullptr;
     static std::once_flag once;
     std::call_once(once, [&lib] {
-        const char *override_name = getenv("TRT_RCCL_LIB");
+        g_bind_started.store(1);
+        const char *override_name = g_override_allowed.load() ? getenv("TRT_RCCL_LIB") : nullptr;
         const char *names[] = {override_name && *override_name ? override_name : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         const int count = override_name && *override_name ? 1 : 3; // an override that cannot be loaded is an error, not a reason to look elsewhere
         void *handle = nullptr;
         for (int i = 0; i < count && !handle; i++)
+        {
             handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+            if (handle)
+                snprintf(g_bound_name, sizeof g_bound_name, "%s%s", override_name && *override_name ? "STAND-IN (TRT_RCCL_LIB): " : "", names[i]);
+        }
         if (!handle)
         {
             const char *why = dlerror();
@@ -174,6 +185,16 @@ struct trt_dist
 };
 
 extern "C" const char *trt_dist_last_error(void) { return g_dist_error; }
+
+extern "C" int trt_dist_allow_rccl_override(int allow)
+{
+    if (g_bind_started.load())
+        return dist_fail(TRT_ERR_NOT_INITIALISED, "RCCL has been bound already (%s): the override must be allowed before the first use", g_bound_name);
+    g_override_allowed.store(allow ? 1 : 0);
+    return TRT_OK;
+}
+
+extern "C" const char *trt_dist_rccl_library(void) { return g_bind_started.load() ? g_bound_name : ""; }
 
 // The root's assembly map (pure host arithmetic, no GPU): frame row -> row of the rank-major gather buffer in which rank r's
 // shard starts at row r * max_rows.  Returns max_rows (the padded shard height), or a negative TRT_ERR_*.
@@ -320,7 +341,12 @@ extern "C" int trt_dist_create(int device, const Scene *scene, const void *id, i
     for (Slot &s : d->slots)
     {
         DIST_TRT(trt_create(device, &s.ctx));
-        DIST_TRT(trt_set_scene(s.ctx, scene));
+        // ONE copy of the scene and of its candidate tables per device: the first slot builds them, the others render from them
+        // (trt_share_scene); only the eye's tables, the scratch and the frame buffers are a slot's own
+        if (&s == &d->slots[0])
+            DIST_TRT(trt_set_scene(s.ctx, scene));
+        else
+            DIST_TRT(trt_share_scene(s.ctx, d->slots[0].ctx));
         if (reserved_cus > 0)
             DIST_TRT(trt_reserve_cus(s.ctx, reserved_cus));
         void *stream = nullptr;
@@ -368,11 +394,14 @@ extern "C" int trt_dist_set_scene(trt_dist *d, const Scene *scene)
 {
     if (!d || !scene)
         return dist_fail(TRT_ERR_ARGUMENT, "NULL argument");
+    for (Slot &s : d->slots) // every slot's frames in flight still read the old tables
+        if (trt_synchronize(s.ctx))
+            return dist_fail(TRT_ERR_HIP, "trt_synchronize: %s", trt_last_error());
     for (Slot &s : d->slots)
-    {
-        const int rc = trt_set_scene(s.ctx, scene); // synchronises the slot's stream first
+    { // the first slot builds the new scene's tables (its old ones stay alive until the last sharer has let go), the others share them
+        const int rc = &s == &d->slots[0] ? trt_set_scene(s.ctx, scene) : trt_share_scene(s.ctx, d->slots[0].ctx);
         if (rc)
-            return dist_fail(rc, "trt_set_scene: %s", trt_last_error());
+            return dist_fail(rc, "%s: %s", &s == &d->slots[0] ? "trt_set_scene" : "trt_share_scene", trt_last_error());
     }
     return TRT_OK;
 }

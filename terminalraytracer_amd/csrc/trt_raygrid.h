@@ -134,7 +134,7 @@ TRT_HD int trt_cubemap_cell(float x, float y, float z, float half_g, float g_max
  * P = 6 m^2 patches by a cube map of the direction centre -> origin (m cells per face side), and every patch k gets its own
  * pair of families: apex  c_i + |r_i| t_k  (t_k inside the unit ball, under the middle of the patch), membership radius
  * |r_i| rho_k + slack with rho_k = the largest distance from t_k to a point of the patch on the unit sphere (0.82 for m = 1,
- * 0.51 for m = 2, 0.36 for m = 3, 0.28 for m = 4 instead of 1).  A ray that starts on patch k has its origin, hence its line,
+ * 0.52 for m = 2, 0.44 for m = 3, 0.33 for m = 4 instead of 1).  A ray that starts on patch k has its origin, hence its line,
  * within that radius of the apex: it is a member -- and trt_rayfamily_member() still checks that for every ray, so a ray
  * looked up in the wrong patch (the FP32 choice of the patch near a patch's edge, a degenerate normal) falls back to the sweep
  * like any other non-member; nothing is taken on trust.  The mirror family of a patch (reflections by the ground of rays that

@@ -563,7 +563,7 @@ TRT_DEV unsigned long long path_cell_patches(const LdsImage &L, const GridView &
     const int here = trt_cubemap_cell((float)(o.x - base_at.x), (float)(o.y - base_at.y), (float)(o.z - base_at.z), 0.5f * (float)G.patch_m,
                                       (float)(G.patch_m - 1), G.patch_m);
     const int k = mirrored ? code & ((1 << TRT_PATCH_SHIFT) - 1) : (of_eye ? 0 : here);
-    fam = f == 0 ? 1 : (!of_eye && !mirrored ? 2 + n + (((f - 2) << TRT_PATCH_SHIFT) | k) : -1);
+    fam = !has ? -1 : (f == 0 ? 1 : (!of_eye && !mirrored ? 2 + n + (((f - 2) << TRT_PATCH_SHIFT) | k) : -1)); // a ray without a family has no successor family either
     const double r_abs = of_eye ? 0.0 : at_mirror[3];
     const double *pr = L.patch + TRT_PATCH_RECORD * k + (mirrored ? 4 : 0);
     const d3 apex = d3{TRT_PATCH_APEX(base_at.x, r_abs, pr[0]), TRT_PATCH_APEX(base_at.y, r_abs, pr[1]), TRT_PATCH_APEX(base_at.z, r_abs, pr[2])};

@@ -72,6 +72,9 @@ SYMBOLS = {
     "trt_set_kernel": (_I, [_VP, _I]),
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
     "trt_set_light_slabs": (_I, [_VP, _I, _I]),
+    "trt_share_scene": (_I, [_VP, _VP]),
+    "trt_scene_info": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(_I), C.POINTER(C.c_double)]),
+    "trt_set_list_pool_words": (_I, [_VP, C.c_size_t]),
     "trt_set_path_grids": (_I, [_VP, _I, _I]),
     "trt_set_path_grids_min_spheres": (_I, [_VP, _I]),
     "trt_set_path_patches": (_I, [_VP, _I]),
@@ -93,6 +96,8 @@ SYMBOLS = {
     "trt_probe_rays": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
     "trt_probe_rays_production": (_I, [_VP, C.POINTER(L.Camera), _VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
     "trt_dist_unique_id": (_I, [_VP]),
+    "trt_dist_allow_rccl_override": (_I, [_I]),
+    "trt_dist_rccl_library": (C.c_char_p, []),
     "trt_dist_create": (_I, [_I, C.POINTER(L.Scene), _VP, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_VP)]),
     "trt_dist_set_scene": (_I, [_VP, C.POINTER(L.Scene)]),
     "trt_dist_render": (_I, [_VP, C.POINTER(L.Camera), _I, _I, C.POINTER(_VP)]),
@@ -197,6 +202,19 @@ class Context:
     def set_light_grids(self, directional_cells, point_cells):
         """cells per side of the light-space candidate tables; 0, 0 = off (trt_set_light_grids)"""
         _check(lib().trt_set_light_grids(self._h, directional_cells, point_cells))
+
+    def share_scene(self, source):
+        """render `source`'s scene from its tables: one copy of every read-only table per device (trt_share_scene)"""
+        _check(lib().trt_share_scene(self._h, source._h))
+
+    def scene_info(self):
+        b, n, t = C.c_ulonglong(), _I(), C.c_double()
+        _check(lib().trt_scene_info(self._h, C.byref(b), C.byref(n), C.byref(t)))
+        return {"table_bytes": b.value, "sharers": n.value, "build_seconds": t.value}
+
+    def set_list_pool_words(self, words):
+        """tests: cap the pool of long candidate lists (trt_set_list_pool_words)"""
+        _check(lib().trt_set_list_pool_words(self._h, words))
 
     def set_light_slabs(self, directional_slabs, point_shells):
         """the light tables' depth coordinate: slabs along a directional light, shells about a point light (trt_set_light_slabs)"""
@@ -415,6 +433,16 @@ def project_scene(scene_data, width, height):
 def _dist_check(code):
     if code != TRT_OK:
         raise TrtError(code, lib().trt_dist_last_error().decode())
+
+
+def dist_allow_rccl_override(allow=True):
+    """TEST HOOK: let TRT_RCCL_LIB name the library bound in RCCL's place; before the first use of RCCL (trt_dist_allow_rccl_override)"""
+    _dist_check(lib().trt_dist_allow_rccl_override(1 if allow else 0))
+
+
+def dist_rccl_library():
+    """which library this process bound for RCCL's entry points ("" before the first use)"""
+    return lib().trt_dist_rccl_library().decode()
 
 
 def dist_unique_id():

@@ -110,8 +110,10 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 def test_rccl_is_bound_by_name_and_may_be_overridden_for_tests(tmp_path):
     """csrc/trt_dist.hip binds its eight RCCL entry points at run time; TRT_RCCL_LIB names another library with the same entry
-    points (the tests' stand-in for several ranks on one GPU, tests/rccl_stub.cpp) and is honoured strictly: a library that cannot
-    be loaded is an error, not a reason to fall back to librccl.  No GPU is needed to make an id."""
+    points (the tests' stand-in for several ranks on one GPU, tests/rccl_stub.cpp).  It is a test hook: honoured only by a process
+    that called trt_dist_allow_rccl_override(1) before its first use of RCCL -- and then strictly: a library that cannot be
+    loaded is an error, not a reason to fall back to librccl -- and IGNORED by every other process (which then binds RCCL itself
+    and says so).  Once RCCL is bound the switch refuses.  No GPU is needed to make an id."""
     import subprocess
     import sys
     stub = os.path.join(T.ROOT, "tests", "_build", "librccl_stub.so")
@@ -121,9 +123,17 @@ def test_rccl_is_bound_by_name_and_may_be_overridden_for_tests(tmp_path):
             pytest.skip("the RCCL stand-in could not be built here")
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from terminalraytracer_amd import hip\n"
-            "try:\n    print('ID', hip.dist_unique_id()[:15])\nexcept hip.TrtError as e:\n    print('ERR', e.code)\n") % T.ROOT
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, TRT_RCCL_LIB=stub), timeout=120)
-    assert "ID b'/trt_rccl_stub_" in out.stdout, (out.stdout, out.stderr[-300:])
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+            "if len(sys.argv) > 1:\n    hip.dist_allow_rccl_override(True)\n"
+            "try:\n    print('ID', hip.dist_unique_id()[:15])\nexcept hip.TrtError as e:\n    print('ERR', e.code)\n"
+            "print('LIB', hip.dist_rccl_library())\n"
+            "try:\n    hip.dist_allow_rccl_override(True)\n    print('LATE ok')\nexcept hip.TrtError as e:\n    print('LATE', e.code)\n") % T.ROOT
+    out = subprocess.run([sys.executable, "-c", code, "allow"], capture_output=True, text=True, env=dict(os.environ, TRT_RCCL_LIB=stub), timeout=120)
+    assert "ID b'/trt_rccl_stub_" in out.stdout and "LIB STAND-IN (TRT_RCCL_LIB): " + stub in out.stdout, (out.stdout, out.stderr[-300:])
+    assert "LATE -5" in out.stdout, out.stdout  # the switch refuses once RCCL is bound
+    out = subprocess.run([sys.executable, "-c", code, "allow"], capture_output=True, text=True,
                          env=dict(os.environ, TRT_RCCL_LIB=str(tmp_path / "no_such_library.so")), timeout=120)
     assert "ERR -5" in out.stdout, (out.stdout, out.stderr[-300:])
+    # without the switch the variable is ignored: the process binds RCCL itself (or fails for want of it), never the stand-in
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, TRT_RCCL_LIB=stub), timeout=120)
+    assert "trt_rccl_stub_" not in out.stdout and "STAND-IN" not in out.stdout, (out.stdout, out.stderr[-300:])
+    assert "LIB librccl" in out.stdout or "LIB /opt/rocm/lib/librccl" in out.stdout or "ERR -5" in out.stdout, out.stdout

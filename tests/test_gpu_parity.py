@@ -441,7 +441,7 @@ def test_trt_dist_with_several_ranks_on_one_gpu(ctx, tmp_path, world, width, hei
         (sky / (f + ".ppm")).write_bytes(T.golden_ppm_raw("colors", f))
     env = dict(os.environ, TRT_RCCL_LIB=stub, TRT_RCCL_STUB_SLOT_MB="8", TRT_RCCL_STUB_DEADLINE="60", GPU_MAX_HW_QUEUES="8")
     procs = [subprocess.Popen([exe, str(sky), str(r), str(world), str(tmp_path / "id"), str(frames), str(width), str(height), str(tile), str(depth),
-                               "0", str(rgb8)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+                               "0", str(rgb8), "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
     outs = []
     try:
         for p in procs:
@@ -461,6 +461,7 @@ def test_trt_dist_with_several_ranks_on_one_gpu(ctx, tmp_path, world, width, hei
         want = render(ctx, scene, width, height, 10, 10)
     fingerprint = T.fnv(T.oracle_rgb8(want)) if rgb8 else T.fnv(want)
     assert f"{frames} frames {width}x{height} on {world} GPU(s)" in outs[0][0] and fingerprint in outs[0][0], (outs[0][0], fingerprint)
+    assert "STAND-IN (TRT_RCCL_LIB)" in outs[0][0], outs[0][0]  # the library says which library it bound in RCCL's place
 
 
 def test_bench_two_ranks_through_the_c_abi_on_one_gpu():
@@ -481,8 +482,8 @@ def test_bench_two_ranks_through_the_c_abi_on_one_gpu():
         port = sock.getsockname()[1]
     env = dict(os.environ, TRT_RCCL_LIB=stub, TRT_RCCL_STUB_DEADLINE="120")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--check", "--steps", "5",
-                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=T.ROOT)
+                          "--master-port", str(port), os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rccl-stand-in", "--check",
+                          "--steps", "5", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=T.ROOT)
     assert out.returncode == 0, out.stderr[-1500:]
     assert "CHECK sharded(2) == single: True" in out.stderr
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -1111,3 +1112,108 @@ def test_render_kernels_keep_four_waves_per_simd(ctx):
         info, variant = ctx.kernel_info(), ctx.render_variant()
         assert variant == {"decoupled": kernel == COMPACT, "workgroup_threads": threads}
         assert info["vgprs"] <= 128 and info["max_blocks_per_cu"] == blocks, (kernel, info)
+
+
+# ---- one copy of the scene's tables per device (trt_share_scene), the pool of long lists ----
+
+def test_contexts_share_one_copy_of_the_scene_tables(ctx):
+    """trt_share_scene: several contexts render ONE scene from one copy of its primitives, cubemap and candidate tables (the frame
+    slots of a trt_dist: TRT.c:1296-1306 builds the scene once, TRT.c:1327-1339 moves the camera per frame); only the eye's two tables
+    -- a slot each in the shared allocation -- are a context's own.  Three sharers render three cameras AT THE SAME TIME (their
+    streams overlap), each frame must be the oracle's; the table setters refuse while shared; trt_set_scene gives a sharer tables
+    of its own again; the tables outlive their first owner."""
+    import torch
+    scene = S.synth_scene(256, T.sky("synth"), T.bench_camera(96, 54))  # patches: the large tables
+    cams = [T.bench_camera(96, 54, t) for t in (1.0, 2.5, 10.0)]
+    want = [T.oracle_render(scene.with_camera(c), 96, 54, 6, 4)[0] for c in cams]
+    owner = hip.Context(0)
+    owner.set_scene(scene)
+    alone = owner.scene_info()
+    sharers = [hip.Context(0) for _ in range(2)]
+    try:
+        for c in sharers:
+            c.share_scene(owner)
+        info = owner.scene_info()
+        assert info["sharers"] == 3 and info["table_bytes"] == alone["table_bytes"] and sharers[0].scene_info() == info
+        bufs = [torch.zeros(54 * 96 * 3, dtype=torch.float64, device="cuda:0") for _ in cams]
+        for _ in range(3):  # frames in flight on three streams, the eye's tables rebuilt per context
+            for c, cam, buf in zip([owner] + sharers, cams, bufs):
+                c.render_device(cam, hip.RowSet.whole(96, 54), 6, 4, buf.data_ptr(), buf.numel() * 8)
+        for c in [owner] + sharers:
+            c.synchronize()
+        for buf, w in zip(bufs, want):
+            assert np.array_equal(bits(buf.cpu().numpy().reshape(54, 96, 3)), bits(w))
+        with pytest.raises(hip.TrtError):
+            sharers[0].set_path_grids(64, 16)
+        with pytest.raises(hip.TrtError):
+            owner.set_light_grids(64, 32)
+        # a sharer that is given another scene builds tables of its own and leaves the others alone
+        other = S.synth_scene(64, T.sky("synth"), T.bench_camera(96, 54), seed=9)
+        sharers[1].set_scene(other)
+        assert sharers[1].scene_info()["sharers"] == 1 and owner.scene_info()["sharers"] == 2
+        got = sharers[1].render_host(other.camera, hip.RowSet.whole(96, 54), 6, 4)
+        assert np.array_equal(bits(got), bits(T.oracle_render(other, 96, 54, 6, 4)[0]))
+        # the first owner goes; the remaining sharer keeps rendering from the tables
+        owner.close()
+        owner = None
+        assert sharers[0].scene_info()["sharers"] == 1
+        got = sharers[0].render_host(cams[2], hip.RowSet.whole(96, 54), 6, 4)
+        assert np.array_equal(bits(got), bits(want[2]))
+        sharers[0].set_path_grids(64, 16)  # alone again: the setters work
+        got = sharers[0].render_host(cams[0], hip.RowSet.whole(96, 54), 6, 4)
+        assert np.array_equal(bits(got), bits(want[0]))
+    finally:
+        for c in sharers + ([owner] if owner else []):
+            c.close()
+
+
+def test_nine_contexts_cannot_share_one_scene(ctx):
+    scene = S.synth_scene(16, T.sky("synth"), T.bench_camera(32, 18))
+    owner = hip.Context(0)
+    owner.set_scene(scene)
+    others = [hip.Context(0) for _ in range(8)]
+    try:
+        for c in others[:7]:
+            c.share_scene(owner)
+        with pytest.raises(hip.TrtError):
+            others[7].share_scene(owner)
+        others[3].close()  # a slot comes free
+        others[7].share_scene(owner)
+        got = others[7].render_host(scene.camera, hip.RowSet.whole(32, 18), 4, 2)
+        assert np.array_equal(bits(got), bits(T.oracle_render(scene, 32, 18, 4, 2)[0]))
+    finally:
+        for i, c in enumerate(others):
+            if i != 3:
+                c.close()
+        owner.close()
+
+
+def test_an_exhausted_list_pool_only_costs_sweeps(ctx):
+    """Lists longer than seven entries live in a pool; a list that finds no room leaves its cell without one and the cell's rays
+    sweep (csrc/trt_capi.hip pack_cell).  The pool's counter keeps counting after exhaustion -- with 64 bits, so that it cannot wrap
+    and hand out words that earlier cells point to.  A dense scene with the pool capped at 64 / 4096 words: nearly every long list
+    is lost, frames and trace counts stay the oracle's, and more traces sweep than with the pool the library would have chosen."""
+    scene = S.synth_scene(256, T.sky("synth"), T.bench_camera(64, 36))
+    big = scene.spheres.copy()
+    big[:, 3] *= 1.6  # fat, overlapping spheres: long lists everywhere
+    scene = scene.with_spheres(big)
+    want, st = T.oracle_render(scene, 64, 36, 6, 4)
+    c = hip.Context(0)
+    try:
+        c.enable_counters(True)
+        swept = {}
+        for cap in (0, 4096, 64):
+            c.set_list_pool_words(cap)
+            c.set_scene(scene)
+            got = c.render_host(scene.camera, hip.RowSet.whole(64, 36), 6, 4)
+            assert np.array_equal(bits(got), bits(want)), cap
+            assert c.read_counters() == (st.path_rays, st.shadow_rays)
+            swept[cap] = c.read_diagnostics()["swept_traces"]
+            info, cells, pool = c.read_path_tables(scene.camera)
+            if cap:
+                assert info["pool_used_scene"] > cap, info  # the counter went on counting past the cap ...
+                lost = sum(1 for x in cells if (int(x) >> 56) == 0xFF)
+                assert lost > 1000, lost    # ... and the lists that found no room say so
+        assert swept[64] > swept[4096] >= swept[0], swept
+    finally:
+        c.close()
