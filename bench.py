@@ -54,6 +54,7 @@ WORKLOADS = {
     "c4": dict(width=3840, height=2160, spheres=64, bounces=8, golden={1.0: "c4_2160p_64sph_b8"},
                text="BASELINE configs[3] on ONE GPU: 3840x2160, SYNTH-v0 64 spheres + checker floor, 2 lights, 8 bounces, 10 rays/pixel"),
     "c3": dict(width=1920, height=1080, spheres=64, bounces=8, golden={1.0: "c3_1080p_64sph_b8"},
+               orbit_golden={0: "c3_1080p_64sph_b8_f0", 19: "c3_1080p_64sph_b8_f19", 59: "c3_1080p_64sph_b8_f59"},
                text="BASELINE configs[2]: 1920x1080, SYNTH-v0 64 spheres seed 1234 + checker floor, 1 directional + 1 point light, "
                     "8 bounces, 10 rays/pixel, 256^2 procedural cubemap, off-screen f64 framebuffer"),
     "c5": dict(width=1920, height=1080, spheres=256, bounces=12, golden={0: "c5_1080p_256sph_b12_f0", 59: "c5_1080p_256sph_b12_f59"},
@@ -238,13 +239,46 @@ def other_configs(hip, host, torch, local, depth, tile_rows):
                          "render_kernel_ms_one_at_a_time": render_ms, "scene_setup_s": setup_s,
                          # one copy of the scene's tables per device, whatever the number of frame slots (trt_share_scene)
                          "scene_tables": d.context(0).scene_info()}
-            prof = (committed_profile() or {}).get("config5") if name == "c5" else None
+            whole = committed_profile() or {}
+            prof = whole.get("config5") if name == "c5" else None
             if prof:
                 out[name]["compute_executed"] = compute_executed(prof.get("compute_executed"), render_ms)
                 out[name]["valu"] = prof.get("valu")
+                # config 5's memory side (its tables leave every cache): COMMITTED PMC passes of this very command
+                alg5 = algorithmic_bytes(w, h, wl["spheres"], SKY_DIM, 1, 1)
+                out[name]["roofline"] = {"bound": "hbm", "achieved": alg5 / (render_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": alg5 / (render_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg5,
+                                         "traffic": prof.get("hbm_bytes_per_launch"), "traffic_over_algorithmic": prof.get("traffic_over_algorithmic"),
+                                         "traffic_breakdown": prof.get("breakdown_bytes"), "traffic_source": prof.get("source"),
+                                         "profile": profile_identity(whole), "kernel_ms": render_ms}
         finally:
             d.close()
     return out
+
+
+def kernel_source_hash():
+    """What the committed profile constants are tied to: a hash of everything the device code is made of (the kernel sources and
+    the compile flags of the Makefile).  tools/make_traffic_json.py stores it when a PMC pass is turned into profiles/traffic.json;
+    a kernel that has changed since shows as profile_matches_build = false in the line."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "terminalraytracer_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hpp", ".h", ".hip")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    with open(os.path.join(ROOT, "Makefile")) as fh:
+        h.update("".join(l for l in fh if l.startswith("HIPFLAGS")).encode())
+    return h.hexdigest()[:16]
+
+
+def profile_identity(prof):
+    """{head, source hash of the kernel the constants were measured on, whether that is the kernel of this tree}"""
+    if not prof:
+        return None
+    here = kernel_source_hash()
+    return {"profile_head": prof.get("head"), "profile_kernel_source_hash": prof.get("kernel_source_hash"), "kernel_source_hash": here,
+            "profile_matches_build": prof.get("kernel_source_hash") == here}
 
 
 def committed_profile():
@@ -268,6 +302,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2, 4 and 5 (rendered and verified after the headline on one GPU)")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the timed frame against the reference's hash")
+    ap.add_argument("--no-moving-camera", action="store_true", help="skip the headline's second loop (the reference's orbiting camera)")
     ap.add_argument("--kernel", type=int, default=0, help="0 production, 1 reference-order (debug)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--rccl-stand-in", action="store_true", help="TEST HOOK: bind the library TRT_RCCL_LIB names in RCCL's place "
@@ -321,6 +356,7 @@ def main():
     rehearsal = world > 1 and args.backend != "nccl" and not stand_in
     carrier = f"cuda:{local}" if args.backend == "nccl" else "cpu"  # where torch.distributed's own tensors live
     fallback_reason = None
+    made = {}
 
     def torch_level_renderer():  # PyTorch-level sharding: trt_render_device per rank, torch.distributed gather
         r = HipShardRenderer(scene, width, height, rank, world, local, bounces, SPP, tile_rows=args.tile_rows, depth=args.depth,
@@ -341,14 +377,16 @@ def main():
         # frame through it on a side thread with a deadline, and let the ranks agree on the outcome.  If any rank failed (an
         # error, or no frame within the deadline), every rank falls back to the PyTorch-level gather and the line says so.
         import threading
-        made, problem = {}, []
+        problem = []
 
         def first_contact():
             try:
                 if os.environ.get("TRT_BENCH_FAIL_DIST"):  # test hook for the fallback
                     raise RuntimeError("TRT_BENCH_FAIL_DIST is set")
+                t_setup = time.perf_counter()
                 d = hip.Dist(local, scene, uid, rank, world, width, height, tile_rows=args.tile_rows, frames_in_flight=args.depth,
                              reserved_cus=args.reserve_cus)
+                made["setup_s"] = time.perf_counter() - t_setup
                 made["dist"] = d
                 frame = d.render(camera_of(0), bounces, SPP)
                 d.synchronize()
@@ -449,6 +487,16 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     seconds = float(elapsed.item())
+    # per rank: what its shard took to render and what its part of the gather took (the slots' most recent frames; HIP events)
+    per_rank = None
+    if hasattr(r, "frame_times"):
+        mine = torch.tensor(list(r.frame_times()), dtype=torch.float64, device=carrier)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(every, mine)
+        else:
+            every = [mine]
+        per_rank = [{"rank": i, "render_ms": round(float(t[0]), 4), "gather_ms": round(float(t[1]), 4)} for i, t in enumerate(every)]
 
     # untimed: the frame the timed loop produced last (and, for the animation, frame 59) against the GENUINE reference's hash
     verified, checks = None, []
@@ -469,6 +517,43 @@ def main():
             barrier()
         if rank == 0:
             verified = bool(checks) and all(c["ok"] for c in checks)
+
+    # The headline as the reference USES the path: main() moves the camera every frame (TRT.c:1327-1339), so the eye's two
+    # candidate tables are rebuilt inside every frame.  The same loop -- same scene, steps, frames in flight -- fed the reference's 60
+    # orbit cameras, the last frame checked against the genuine reference's hash of that very frame.  (The orbit sees other
+    # frames than the still, so the ray counts are those of its own cameras.)
+    moving = None
+    if world == 1 and workload == "c3" and args.animation == 0 and args.kernel == 0 and args.sky_dim == SKY_DIM and not args.no_moving_camera:
+        orbit = animation_cameras(width, height, 60)
+        ctx0.enable_counters(True)
+        orbit_path = []
+        for cam in orbit[:max(1, min(args.steps, 60))]:
+            ctx0.render_device(cam, rowset, bounces, SPP, scratch.data_ptr(), scratch.numel() * 8)
+            orbit_path.append(ctx0.read_counters()[0])
+        ctx0.enable_counters(False)
+        for i in range(args.warmup):
+            render(orbit[i % 60])
+        barrier()
+        t1 = time.perf_counter()
+        last_moving = None
+        for i in range(args.steps):
+            last_moving = render(orbit[i % 60])
+        barrier()
+        moving_seconds = time.perf_counter() - t1
+        rays = float(sum(orbit_path[i % len(orbit_path)] for i in range(args.steps)))
+        moving = {"value": rays / moving_seconds, "unit": "rays/s", "ms_per_step": moving_seconds / args.steps * 1e3, "steps": args.steps,
+                  "camera": "the reference's orbit, t = f/60: a new camera and new eye tables every frame (TRT.c:1327-1339)",
+                  "verification": [], "verified": None}
+        if not args.no_verify:
+            index = (args.steps - 1) % 60
+            probes = [(index, last_moving)] if index in wl["orbit_golden"] else [(59, None), (0, None)]
+            for index, frame in probes:
+                frame = frame if frame is not None else render(orbit[index])
+                torch.cuda.synchronize()
+                want = golden_hash(wl["orbit_golden"][index])
+                got = host.fnv1a64(fetch(frame))
+                moving["verification"].append({"frame": wl["orbit_golden"][index], "fnv": got, "reference_fnv": want["fb_fnv"], "ok": got == want["fb_fnv"]})
+            moving["verified"] = all(c["ok"] for c in moving["verification"])
 
     if rank == 0:
         ms_step = seconds / args.steps * 1e3
@@ -501,6 +586,13 @@ def main():
                        "camera": "static: the eye's two candidate tables are built once, before the timed region (an orbit rebuilds them every "
                                  "frame, ~0.06 ms: see configs.c5)" if args.animation == 0 else "a new camera every frame (the eye's tables are rebuilt per frame, inside the timed region)"},
             "frames_per_s": args.steps / seconds,
+            # the same loop under the reference's real usage: a new camera every frame (its own ray counts; see `moving_camera`)
+            "value_moving_camera": moving["value"] if moving else None,
+            "moving_camera": moving,
+            "scene_setup_s": made.get("setup_s") if not rehearsal else None,
+            "scene_tables": ctx0.scene_info(),
+            "per_rank": per_rank,
+            "rccl_library": hip.dist_rccl_library() if world > 1 and not rehearsal else None,
             "rays_per_frame": {"path": path_mean, "shadow": float(np.mean(shadow_cam))},
             "all_rays_per_s": (path_timed + shadow_timed) / seconds,
             "frames_in_flight": args.depth,
@@ -511,6 +603,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (prof or {}).get("hbm_bytes_per_launch"),
                          "traffic_source": (prof or {}).get("source"),
+                         "profile": profile_identity(prof),
                          "algorithmic_bytes": alg, "kernel": variant_name, "kernel_ms": render_ms_avg,
                          "achieved_by_step": alg / (ms_step * 1e-3) / 1e9,
                          "traffic_over_algorithmic": ((prof or {}).get("hbm_bytes_per_launch") or 0) / alg if prof else None,
@@ -550,11 +643,22 @@ def main():
             except Exception as e:  # the checker libraries are built by __graft_entry__.build(); never lose the GPU line over them
                 out["cpu_baseline"] = {"value": None, "unit": "path rays/s", "cores": 1, "kind": "port", "sample": "not measured",
                                        "error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(out))
-        configs = out.get("configs") or {}
-        if any(isinstance(c, dict) and c.get("verified") is False for c in configs.values()):
+        # the line's "verified" covers everything in it: the headline's frame, the moving-camera frame and the other configs; a
+        # config that could not be measured at all (an exception) counts as unverified too
+        if moving and moving["verified"] is False:
             verified = False
-            checks = checks + [v for c in configs.values() if isinstance(c, dict) for v in c.get("verification", []) if not v["ok"]]
+            checks = checks + [v for v in moving["verification"] if not v["ok"]]
+        configs = out.get("configs")
+        if configs is not None and not args.no_verify:
+            if "error" in configs:
+                verified = False
+                checks = checks + [{"frame": "configs c2/c4/c5", "ok": False, "error": configs["error"]}]
+            for c in configs.values():
+                if isinstance(c, dict) and c.get("verified") is False:
+                    verified = False
+                    checks = checks + [v for v in c.get("verification", []) if not v["ok"]]
+        out["verified"], out["verification"] = verified, checks
+        print(json.dumps(out))
     if r is not None:
         r.close()
     if world > 1:

@@ -57,6 +57,15 @@ int render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_
  * [0, 1) convert as the reference's cast does on x86-64. */
 int trt_render_frame_rgb8(const Scene *scene, int width, int height, int bounce_limit, int rays_per_pixel, unsigned char *rgb);
 
+/* project_scene is a pure function of *scene (TRT.c:966): a caller may move a sphere before every call.  The drop-in entries
+ * compare the primitives with the previous call's; a scene that has changed on `moving_after` consecutive calls counts as MOVING
+ * and its candidate tables are rebuilt per call the cheap way (one family per sphere instead of 24 patches: ~4 ms instead of ~100 ms
+ * at 256 spheres), and after `still_after` consecutive unchanged calls the full tables are built once.  moving_after = 0: every
+ * change builds the full tables.  Defaults 2 and 3.  Frames are bit-identical whichever tables serve them.
+ * trt_scene_is_moving: 1 while the default context treats its scene as moving. */
+int trt_set_scene_policy(int moving_after, int still_after);
+int trt_scene_is_moving(void);
+
 /* Default-context management for the two calls above.  trt_init is optional (device 0 otherwise). */
 int trt_init(int device);
 int trt_shutdown(void);
@@ -341,6 +350,10 @@ int trt_dist_fetch(trt_dist *d, const void *d_frame, Vector *pixels);
  * which rank r's shard starts at row r * max_rows.  Returns max_rows, the height every shard is padded to. */
 int trt_dist_source_rows(int width, int height, int tile_rows, int world, int *source_row);
 int trt_dist_info(const trt_dist *d, int *rank, int *world, int *local_rows, int *max_rows, int *frames_in_flight);
+/* Diagnostics, averaged over the frame slots' most recent frames (synchronises): this rank's render time (render kernel + ordered
+ * mean) and the time its part of the gather took on the communicator's stream (send, or the receives and the assembly kernel on
+ * the root); 0 where there was nothing to measure.  One number pair per rank makes a multi-GPU run diagnosable from one line. */
+int trt_dist_frame_times(trt_dist *d, float *render_ms, float *gather_ms);
 /* the renderer context of a slot (counters, kernel times, kernel selection); owned by d */
 trt_context *trt_dist_context(trt_dist *d, int slot);
 int trt_dist_destroy(trt_dist *d);

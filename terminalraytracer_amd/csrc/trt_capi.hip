@@ -161,6 +161,7 @@ struct SceneTables
     double ground_built[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     std::vector<double> h_spheres, h_dir, h_point; // what the tables on the device were built from
     unsigned eye_slots_taken = 0;                  // bit s: a context renders with the eye tables of slot s
+    bool built_for_moving_scene = false;           // the cheap tables of a scene that changes from call to call
     double build_seconds = 0.0;                    // host time of the last table build (trt_scene_info)
     ~SceneTables()
     {
@@ -194,6 +195,12 @@ struct trt_context
     int path_min_spheres = TRT_PATHGRID_MIN_SPHERES;                      // scenes with fewer spheres sweep
     int path_patches = TRT_PATHGRID_PATCHES;                              // m of the spheres' sub-families; -1: by the number of spheres
     size_t list_pool_cap = 0;                                             // trt_set_list_pool_words: cap on the scene's part of the pool (0 = automatic)
+    // project_scene is a pure function of *scene (TRT.c:966): a caller of the drop-in entries may move a sphere before every call.
+    // The drop-in layer counts consecutive calls whose primitives differ from the call before; from the second on the scene
+    // counts as MOVING and its tables are built the cheap way (one family per sphere instead of 24 patches: 1/24 of the cells,
+    // the dominant cost at 128+ spheres), and once it has been still for a few calls the full tables are built (trt_set_scene_policy).
+    int scene_changes_in_a_row = 0, scene_still_calls = 0;
+    bool moving_scene = false;
     double eye_built[3] = {0.0, 0.0, 0.0};
     bool eye_tables_valid = false;
     DeviceBuffer<double> d_ior; // refraction extension: per sphere, > 0 = index of refraction
@@ -504,6 +511,8 @@ int patches_for(const trt_context *ctx, int n)
 {
     if (ctx->path_patches >= 0)
         return std::min(ctx->path_patches, TRT_PATCH_MAX_M);
+    if (ctx->moving_scene) // tables that live for one frame: the 24-fold cells of the patches cost more to build than they save
+        return 0;
     int m = n >= TRT_PATCHES_FROM_SPHERES ? 2 : 0;
     const unsigned long long per_table = 6ull * (unsigned long long)ctx->path_g_sph * (unsigned long long)ctx->path_g_sph;
     while (m > 0 && 2ull * (unsigned long long)n * (6ull * m * m) * per_table * 12ull > kAutoPatchBudgetBytes) // 8 B a cell + half a pool word
@@ -659,8 +668,11 @@ int refresh_occupancy(trt_context *ctx)
     return TRT_OK;
 }
 
-// everything of the scene except camera and skybox
-int upload_primitives(trt_context *ctx, const Scene *scene)
+// trt_set_scene_policy: a scene counts as moving from this many consecutive changed calls on, and as still again after this many unchanged ones
+int g_moving_after = 2, g_still_after = 3;
+
+// everything of the scene except camera and skybox.  per_call: the drop-in entries, which are handed the scene with every frame
+int upload_primitives(trt_context *ctx, const Scene *scene, bool per_call = false)
 {
     const int n = scene->num_spheres, nd = scene->num_directional_lights, np = scene->num_point_lights;
     if (n < 0 || nd < 0 || np < 0)
@@ -695,10 +707,26 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
 
     // the light-space tables only change with the spheres and the lights (a render loop usually moves the camera only)
     const double *hs = (const double *)scene->spheres, *hd = (const double *)scene->directional_lights, *hp = (const double *)scene->point_lights;
-    const bool same = ctx->T->h_spheres.size() == (size_t)n * 9 && ctx->T->h_dir.size() == (size_t)nd * 6 && ctx->T->h_point.size() == (size_t)np * 7 &&
-                      (!n || !memcmp(ctx->T->h_spheres.data(), hs, (size_t)n * sizeof(Sphere))) &&
-                      (!nd || !memcmp(ctx->T->h_dir.data(), hd, (size_t)nd * sizeof(DirectionalLight))) &&
-                      (!np || !memcmp(ctx->T->h_point.data(), hp, (size_t)np * sizeof(PointLight))) &&
+    const bool same_primitives = ctx->T->h_spheres.size() == (size_t)n * 9 && ctx->T->h_dir.size() == (size_t)nd * 6 && ctx->T->h_point.size() == (size_t)np * 7 &&
+                                 (!n || !memcmp(ctx->T->h_spheres.data(), hs, (size_t)n * sizeof(Sphere))) &&
+                                 (!nd || !memcmp(ctx->T->h_dir.data(), hd, (size_t)nd * sizeof(DirectionalLight))) &&
+                                 (!np || !memcmp(ctx->T->h_point.data(), hp, (size_t)np * sizeof(PointLight))) &&
+                                 !memcmp(ctx->T->ground_built, &scene->ground, sizeof ctx->T->ground_built);
+    if (!per_call) // trt_set_scene: "once per scene" -- always the full tables
+        ctx->moving_scene = false, ctx->scene_changes_in_a_row = ctx->scene_still_calls = 0;
+    else if (!same_primitives)
+    {
+        ctx->scene_still_calls = 0;
+        if (++ctx->scene_changes_in_a_row >= g_moving_after && g_moving_after > 0)
+            ctx->moving_scene = true;
+    }
+    else
+    {
+        ctx->scene_changes_in_a_row = 0;
+        if (++ctx->scene_still_calls >= g_still_after)
+            ctx->moving_scene = false; // still again: the tables below are promoted to the full ones
+    }
+    const bool same = same_primitives && ctx->T->built_for_moving_scene == ctx->moving_scene &&
                       ctx->T->grids_built_for[0] == ctx->dirgrid_cells && ctx->T->grids_built_for[1] == ctx->pointgrid_cells &&
                       ctx->T->grids_built_for[2] == ctx->dirgrid_slabs && ctx->T->grids_built_for[3] == ctx->pointgrid_shells &&
                       ctx->T->path_built_for[0] == ctx->path_g_eye && ctx->T->path_built_for[1] == ctx->path_g_sph &&
@@ -709,6 +737,7 @@ int upload_primitives(trt_context *ctx, const Scene *scene)
         ctx->T->h_spheres.assign(hs, hs + (size_t)n * 9);
         ctx->T->h_dir.assign(hd, hd + (size_t)nd * 6);
         ctx->T->h_point.assign(hp, hp + (size_t)np * 7);
+        ctx->T->built_for_moving_scene = ctx->moving_scene;
         const int rc = build_tables(ctx, cs, (const double *)&scene->ground);
         if (rc)
         {
@@ -1987,7 +2016,7 @@ static int refresh_default_scene(trt_context *ctx, const Scene *scene)
     const double t_begin = host_now_ms();
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->have_scene = false;
-    int rc = upload_primitives(ctx, scene);
+    int rc = upload_primitives(ctx, scene, true);
     if (rc)
         return rc;
     bool same_sky = ctx->sky_dim == scene->skybox.dim;
@@ -2004,6 +2033,27 @@ static int refresh_default_scene(trt_context *ctx, const Scene *scene)
     if (print_host_times())
         fprintf(stderr, "trt_render_frame: scene upload %.3f ms\n", host_now_ms() - t_begin);
     return TRT_OK;
+}
+
+// The drop-in entries (project_scene, trt_render_frame, trt_render_frame_rgb8) take the scene with every call.  A scene whose
+// primitives differ from the previous call's on `moving_after` consecutive calls is treated as MOVING: its candidate tables are
+// rebuilt per call the cheap way (one family per sphere, no patches); after `still_after` consecutive unchanged calls the full
+// tables are built once.  moving_after = 0: never (every change builds the full tables).  Defaults 2 and 3.  Frames are
+// bit-identical either way.  *moving (may be NULL): whether the default context currently treats its scene as moving.
+extern "C" int trt_set_scene_policy(int moving_after, int still_after)
+{
+    if (moving_after < 0 || still_after < 1)
+        return fail(TRT_ERR_ARGUMENT, "scene policy %d, %d", moving_after, still_after);
+    std::lock_guard<std::mutex> turn(g_default_mutex);
+    g_moving_after = moving_after;
+    g_still_after = still_after;
+    return TRT_OK;
+}
+
+extern "C" int trt_scene_is_moving(void)
+{
+    std::lock_guard<std::mutex> turn(g_default_mutex);
+    return g_default && g_default->moving_scene ? 1 : 0;
 }
 
 extern "C" int trt_render_frame(const Scene *scene, Screen *screen, int bounce_limit, int rays_per_pixel)

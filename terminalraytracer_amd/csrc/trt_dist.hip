@@ -162,7 +162,8 @@ struct Slot
     // the same three for the frame as the emitter's bytes, 3 per pixel (trt_dist_enable_rgb8)
     unsigned char *shard8 = nullptr, *gathered8 = nullptr, *frame8 = nullptr;
     hipEvent_t rendered = nullptr, consumed = nullptr;
-    bool used = false;
+    hipEvent_t gather_begin = nullptr; // on the communicator's stream once the shard is rendered; `consumed` ends the gather (both with timing)
+    bool used = false, gathered_once = false;
 };
 
 } // namespace
@@ -261,6 +262,8 @@ extern "C" int trt_dist_destroy(trt_dist *d)
             (void)hipEventDestroy(s.rendered);
         if (s.consumed)
             (void)hipEventDestroy(s.consumed);
+        if (s.gather_begin)
+            (void)hipEventDestroy(s.gather_begin);
         if (s.gathered)
             (void)hipFree(s.gathered);
         else if (s.shard)
@@ -361,7 +364,8 @@ extern "C" int trt_dist_create(int device, const Scene *scene, const void *id, i
         else
             DIST_HIP_B(hipMalloc((void **)&s.shard, (size_t)std::max(d->max_rows, 1) * row_doubles * sizeof(double)));
         DIST_HIP_B(hipEventCreateWithFlags(&s.rendered, hipEventDisableTiming));
-        DIST_HIP_B(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
+        DIST_HIP_B(hipEventCreate(&s.consumed));     // with timing: trt_dist_frame_times
+        DIST_HIP_B(hipEventCreate(&s.gather_begin));
     }
     if (d->through_comm)
     {
@@ -475,6 +479,8 @@ static int render_and_gather(trt_dist *d, const Camera *camera, int bounce_limit
     Rccl *R = rccl();
     if (hipEventRecord(s.rendered, s.stream) != hipSuccess || hipStreamWaitEvent(d->comm_stream, s.rendered, 0) != hipSuccess)
         return poison(dist_fail(TRT_ERR_HIP, "event hand-over to the communicator's stream failed"));
+    (void)hipEventRecord(s.gather_begin, d->comm_stream); // diagnostics only (trt_dist_frame_times)
+    s.gathered_once = true;
     // the group is always closed, whatever happens inside it: the first error is kept and returned after ncclGroupEnd
     ncclResult_t first = R->GroupStart();
     const bool opened = first == ncclSuccess;
@@ -538,6 +544,36 @@ extern "C" int trt_dist_synchronize(trt_dist *d)
         DIST_HIP(hipStreamSynchronize(s.stream));
     if (d->comm_stream)
         DIST_HIP(hipStreamSynchronize(d->comm_stream));
+    return TRT_OK;
+}
+
+// Diagnostics of the most recent frame of every slot, averaged over the slots: this rank's render time (render kernel + ordered
+// mean, HIP events on the slot's stream) and the time its part of the gather took on the communicator's stream (from the moment
+// the shard was rendered AND the stream was free, to the end of the send / of the last receive and the assembly): what makes a
+// multi-GPU run slower than its slowest shard shows here, per rank.  Synchronises.  gather_ms = 0 without a communicator.
+extern "C" int trt_dist_frame_times(trt_dist *d, float *render_ms, float *gather_ms)
+{
+    if (!d)
+        return dist_fail(TRT_ERR_ARGUMENT, "d is NULL");
+    const int rc = trt_dist_synchronize(d);
+    if (rc)
+        return rc;
+    double render = 0.0, gather = 0.0;
+    int renders = 0, gathers = 0;
+    for (Slot &s : d->slots)
+    {
+        float r = 0.0f, m = 0.0f;
+        if (s.used && d->local_rows > 0 && trt_render_kernel_times(s.ctx, &r, &m, 1) == 1)
+            render += r + m, renders++;
+        float g = 0.0f;
+        if (s.gathered_once && hipEventElapsedTime(&g, s.gather_begin, s.consumed) == hipSuccess)
+            gather += g, gathers++;
+    }
+    (void)hipGetLastError();
+    if (render_ms)
+        *render_ms = renders ? (float)(render / renders) : 0.0f;
+    if (gather_ms)
+        *gather_ms = gathers ? (float)(gather / gathers) : 0.0f;
     return TRT_OK;
 }
 

@@ -73,6 +73,8 @@ SYMBOLS = {
     "trt_set_light_grids": (_I, [_VP, _I, _I]),
     "trt_set_light_slabs": (_I, [_VP, _I, _I]),
     "trt_share_scene": (_I, [_VP, _VP]),
+    "trt_set_scene_policy": (_I, [_I, _I]),
+    "trt_scene_is_moving": (_I, []),
     "trt_scene_info": (_I, [_VP, C.POINTER(C.c_ulonglong), C.POINTER(_I), C.POINTER(C.c_double)]),
     "trt_set_list_pool_words": (_I, [_VP, C.c_size_t]),
     "trt_set_path_grids": (_I, [_VP, _I, _I]),
@@ -96,6 +98,7 @@ SYMBOLS = {
     "trt_probe_rays": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
     "trt_probe_rays_production": (_I, [_VP, C.POINTER(L.Camera), _VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
     "trt_dist_unique_id": (_I, [_VP]),
+    "trt_dist_frame_times": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "trt_dist_allow_rccl_override": (_I, [_I]),
     "trt_dist_rccl_library": (C.c_char_p, []),
     "trt_dist_create": (_I, [_I, C.POINTER(L.Scene), _VP, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_VP)]),
@@ -488,6 +491,12 @@ class Dist:
         out = np.zeros((self.height, self.width, 3), dtype=np.float64)
         _dist_check(lib().trt_dist_fetch(self._h, _VP(device_frame), out.ctypes.data))
         return out
+
+    def frame_times(self):
+        """(render_ms, gather_ms) of this rank, averaged over the slots' most recent frames (trt_dist_frame_times)"""
+        r, g = C.c_float(), C.c_float()
+        _dist_check(lib().trt_dist_frame_times(self._h, C.byref(r), C.byref(g)))
+        return float(r.value), float(g.value)
 
     def enable_rgb8(self):
         """byte buffers for frames gathered as the emitter's (int)(c*255) triplets (trt_dist_enable_rgb8)"""

@@ -164,7 +164,8 @@ def test_counters_equal_reference_trace_ray_counts(ctx):
         ctx.enable_counters(False)
 
 
-FULL = ["c3_1080p_64sph_b8", "c2_1080p_8sph_b4", "c4_2160p_64sph_b8", "c5_1080p_256sph_b12_f0", "c5_1080p_256sph_b12_f59"]
+FULL = ["c3_1080p_64sph_b8", "c2_1080p_8sph_b4", "c4_2160p_64sph_b8", "c5_1080p_256sph_b12_f0", "c5_1080p_256sph_b12_f59",
+        "c3_1080p_64sph_b8_f19"]  # the last: the headline's scene seen from the reference's moving camera (bench.py's value_moving_camera)
 
 
 @pytest.mark.parametrize("name", FULL)
@@ -1217,3 +1218,47 @@ def test_an_exhausted_list_pool_only_costs_sweeps(ctx):
         assert swept[64] > swept[4096] >= swept[0], swept
     finally:
         c.close()
+
+
+def test_a_scene_that_changes_with_every_call_of_the_drop_in_entry(ctx):
+    """project_scene is a pure function of *scene (TRT.c:966): a caller may move a sphere before EVERY call.  The drop-in layer then
+    stops building the full tables (24 patches per sphere at 256 spheres: ~0.1 s) and builds the cheap ones (one family per sphere)
+    per call; once the scene has been still for three calls it builds the full ones again.  20 calls with a sphere moved before
+    each, then 5 without: every frame is the oracle's, the layer says when it treats the scene as moving, and a moving call is
+    several times cheaper than a full build."""
+    import time
+    scene = S.synth_scene(256, T.sky("synth"), T.bench_camera(96, 54))
+    lib = hip.lib()
+    hip._check(lib.trt_set_scene_policy(2, 3))
+    try:
+        took, moving = [], []
+        for i in range(25):
+            if i < 20:
+                sph = scene.spheres.copy()
+                sph[i % 256, 1] += 0.01 * (i + 1)
+                scene = scene.with_spheres(sph)
+            t0 = time.perf_counter()
+            got = hip.render_frame(scene, 96, 54, 6, 4)
+            took.append(time.perf_counter() - t0)
+            moving.append(lib.trt_scene_is_moving())
+            if i in (0, 1, 2, 7, 19, 20, 22, 23, 24):
+                want, _ = T.oracle_render(scene, 96, 54, 6, 4)
+                assert np.array_equal(bits(got), bits(want)), i
+        # call 0: the first scene (full tables); call 1: the second change in a row -> moving from here on; calls 20, 21 unchanged
+        # but not yet still for three calls; call 22: still -> promoted (full build); 23, 24: nothing to build
+        assert moving == [0] + [1] * 21 + [0] * 3, moving
+        full, cheap, idle = took[22], float(np.median(took[3:20])), float(np.median(took[23:]))
+        print(f"\nper call at 256 spheres, 96x54: full tables {full * 1e3:.1f} ms, moving scene {cheap * 1e3:.1f} ms, unchanged {idle * 1e3:.1f} ms")
+        assert cheap < 0.5 * full and idle < cheap
+        # the policy can be switched off: every change builds the full tables
+        hip._check(lib.trt_set_scene_policy(0, 3))
+        sph = scene.spheres.copy()
+        for i in range(3):
+            sph[5, 0] += 0.02
+            scene = scene.with_spheres(sph.copy())
+            got = hip.render_frame(scene, 96, 54, 6, 4)
+            assert lib.trt_scene_is_moving() == 0
+        want, _ = T.oracle_render(scene, 96, 54, 6, 4)
+        assert np.array_equal(bits(got), bits(want))
+    finally:
+        hip._check(lib.trt_set_scene_policy(2, 3))

@@ -28,3 +28,27 @@ for i in range(n):
     call()
 dt = (time.perf_counter() - t0) / n
 print(f"... with one sphere moved before every call (tables rebuilt): {dt * 1e3:.2f} ms/frame")
+
+# the 256-sphere scene of config 5 (24 patches per sphere: ~0.1 s of table build): a sphere moved before every call.  From the
+# second changed call on the drop-in layer treats the scene as moving and builds the cheap tables per call (trt_set_scene_policy)
+scene = bench.build_scene("c5")
+sc = scene.as_scene()
+call5 = lambda: hip._check(hip.lib().trt_render_frame(C.byref(sc), C.byref(screen), 12, bench.SPP))
+for policy, label in (((2, 3), "moving-scene policy on (default)"), ((0, 3), "policy off: every change builds the full tables")):
+    hip._check(hip.lib().trt_set_scene_policy(*policy))
+    for _ in range(6):  # a new scene, then still for three calls: the full tables are in place before anything is timed
+        call5()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        call5()
+    still = (time.perf_counter() - t0) / 10
+    per = []
+    for i in range(12):
+        scene.spheres[0, 1] += 1e-3
+        sc = scene.as_scene()
+        t0 = time.perf_counter()
+        call5()
+        per.append(time.perf_counter() - t0)
+    print(f"256 spheres, 1080p, 12 bounces, {label}: unchanged scene {still * 1e3:.2f} ms/call; a sphere moved before every call: "
+          f"first {per[0] * 1e3:.1f} ms, then median {np.median(per[2:]) * 1e3:.2f} ms/call")
+hip._check(hip.lib().trt_set_scene_policy(2, 3))

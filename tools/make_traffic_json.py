@@ -2,14 +2,22 @@
 HBM bytes per launch (FETCH_SIZE / WRITE_SIZE from separate passes, gfx950 correction of MI355X_MICROARCH.md applied) and the
 VALU counters.  The FP64 instruction counters (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64) give the EXECUTED FP64 work of a launch, for config 3 and,
 from a second summary, for config 5.
-usage: python tools/make_traffic_json.py <pmc_summary.json> <tag> [<c5_pmc_summary.json>] [<round dir, default r03>] > profiles/traffic.json"""
+The record names the kernel it was measured on: `head` (git HEAD of the tree the profile was taken from -- run this script in that
+tree) and `kernel_source_hash` (bench.kernel_source_hash(): the kernel sources + compile flags); bench.py compares the latter with
+its own tree and says profile_matches_build = false when the constants are stale.
+usage: python tools/make_traffic_json.py <pmc_summary.json> <tag> [<c5_pmc_summary.json>] [<round dir, default r04>] > profiles/traffic.json"""
 import json
+import os
+import subprocess
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
 
 s = json.load(open(sys.argv[1]))
 tag = sys.argv[2]
 c5 = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else None
-rnd = sys.argv[4] if len(sys.argv) > 4 else "r03"
+rnd = sys.argv[4] if len(sys.argv) > 4 else "r04"
 
 
 def executed_fp64(counters, kernel_name, where):
@@ -34,7 +42,13 @@ render_w, render_f = m(R, "WRITE_SIZE") * KB, m(R, "FETCH_SIZE") * KB
 reduce_w, reduce_f = m(D, "WRITE_SIZE") * KB, m(D, "FETCH_SIZE") * KB
 total = render_w + 2 * render_f + reduce_w + 2 * reduce_f
 gui = m(R, "GRBM_GUI_ACTIVE") / 8.0
+try:
+    head = subprocess.check_output(["git", "rev-parse", "HEAD"], cwd=bench.ROOT, text=True).strip()
+    dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "terminalraytracer_amd/csrc", "Makefile"], cwd=bench.ROOT, text=True).strip())
+except Exception:  # noqa: BLE001
+    head, dirty = None, None
 out = {
+    "head": head, "head_dirty_kernel_sources": dirty, "kernel_source_hash": bench.kernel_source_hash(),
     "workload": "bench.py default (1920x1080, 64 spheres, 8 bounces, 10 rays/pixel), production kernels " + rk.replace("trt::", "") + " + reduce_samples_kernel, --depth 1",
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace; profiles/{rnd}/{tag}_pmc_summary.txt (tools/profile_round.sh); means over the dispatches",
     "per_launch_KB": {"render_rounds_kernel": {"FETCH_SIZE": m(R, "FETCH_SIZE"), "WRITE_SIZE": m(R, "WRITE_SIZE")},
@@ -66,8 +80,22 @@ if c5:
     ck = next(k for k in c5 if "render_rounds_kernel<false" in k)
     C = c5[ck]
     gui5 = m(C, "GRBM_GUI_ACTIVE") / 8.0
+    alg5 = bench.algorithmic_bytes(1920, 1080, 256, 256, 1, 1)
+    mem5 = {}
+    if "FETCH_SIZE" in C and "WRITE_SIZE" in C:
+        dk5 = next(k for k in c5 if "reduce_samples_kernel" in k)
+        D5 = c5[dk5]
+        rw, rf, dw, df = m(C, "WRITE_SIZE") * KB, m(C, "FETCH_SIZE") * KB, m(D5, "WRITE_SIZE") * KB, m(D5, "FETCH_SIZE") * KB
+        total5 = rw + 2 * rf + dw + 2 * df
+        mem5 = {"per_launch_KB": {"render_rounds_kernel": {"FETCH_SIZE": m(C, "FETCH_SIZE"), "WRITE_SIZE": m(C, "WRITE_SIZE")},
+                                  "reduce_samples_kernel": {"FETCH_SIZE": m(D5, "FETCH_SIZE"), "WRITE_SIZE": m(D5, "WRITE_SIZE")}},
+                "hbm_bytes_per_launch": round(total5), "algorithmic_bytes_per_launch": alg5, "traffic_over_algorithmic": total5 / alg5,
+                "breakdown_bytes": {"scratch_write_render": round(rw), "scratch_read_reduce": round(2 * df), "framebuffer_write_reduce": round(dw),
+                                    "cubemap_and_table_reads_render_upper_bound": round(2 * rf)},
+                "source": f"profiles/{rnd}/{tag}_c5_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; x2 on reads as for config 3)"}
     out["config5"] = {
         "workload": "bench.py --animation 60 --depth 1 (1920x1080, 256 spheres, 12 bounces, orbit), " + ck.replace("trt::", ""),
+        **mem5,
         "valu": {"SQ_INSTS_VALU_per_launch": m(C, "SQ_INSTS_VALU"), "valu_busy_measured": 4.0 * m(C, "SQ_ACTIVE_INST_VALU") / (1024 * gui5),
                  "lane_activity": m(C, "SQ_THREAD_CYCLES_VALU") / (64.0 * m(C, "SQ_ACTIVE_INST_VALU")),
                  "source": f"profiles/{rnd}/{tag}_c5_pmc_summary.txt"},

@@ -10,7 +10,7 @@ O=gpurun_out/$tag
 mkdir -p $O
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err
 timeout -k 10 300 python3 bench.py --animation 60 --no-cpu-baseline > $O/bench_anim.json 2> $O/bench_anim.err
-B="python3 bench.py --no-cpu-baseline --no-verify --no-configs"
+B="python3 bench.py --no-cpu-baseline --no-verify --no-configs --no-moving-camera"
 timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_d1 -o p -- $B --depth 1 > $O/bench_d1_prof.json
 timeout -k 10 200 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_d2 -o p -- $B > $O/bench_d2_prof.json
 S="--depth 1 --steps 4 --warmup 1"
@@ -28,7 +28,10 @@ timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d $O/c5_
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES -d $O/c5_pmc_sq -o p -- $A > /dev/null
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/c5_pmc_sq2 -o p -- $A > /dev/null
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc $F64 -d $O/c5_pmc_f64 -o p -- $A > /dev/null
-python3 tools/pmc_summary.py $O/c5_pmc_sq $O/c5_pmc_sq2 $O/c5_pmc_f64 --json $O/c5_pmc_summary.json > $O/c5_pmc_summary.txt
+# config 5's memory side: its tables (hundreds of MB of list cells) leave every cache -- HBM bytes in separate passes, as for config 3
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/c5_pmc_fetch -o p -- $A > /dev/null
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/c5_pmc_write -o p -- $A > /dev/null
+python3 tools/pmc_summary.py $O/c5_pmc_fetch $O/c5_pmc_write $O/c5_pmc_sq $O/c5_pmc_sq2 $O/c5_pmc_f64 --json $O/c5_pmc_summary.json > $O/c5_pmc_summary.txt
 find $O -name "*kernel_stats.csv" | head
 cat $O/pmc_summary.txt | grep -v "<true>"
 cat $O/c5_pmc_summary.txt | grep -v "<true>"
