@@ -51,7 +51,11 @@ oracle:
 
 # TEST INFRASTRUCTURE: a stand-in for the eight RCCL entry points trt_dist.hip binds, so that several ranks can share the one GPU of a
 # test box (selected by TRT_RCCL_LIB, tests only)
-stub: tests/_build/librccl_stub.so
+stub: tests/_build/librccl_stub.so tests/_build/dist_ranks
+# TEST HOST: several ranks of trt_dist_* as threads of one process (the 8-way split of BASELINE configs 4 and 5 on one GPU)
+tests/_build/dist_ranks: tests/dist_ranks.c $(LIB) include/trt_hip.h include/trt_host.h
+	@mkdir -p tests/_build
+	$(CC) -O2 -std=gnu11 -Iinclude -o $@ $< -Lterminalraytracer_amd -ltrt_hip -lpthread -lm -Wl,-rpath,'$$ORIGIN/../../terminalraytracer_amd'
 tests/_build/librccl_stub.so: tests/rccl_stub.cpp
 	@mkdir -p tests/_build
 	g++ -O2 -fPIC -shared -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -o $@ $< -L/opt/rocm/lib -lamdhip64 -lrt -lpthread

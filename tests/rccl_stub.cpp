@@ -12,6 +12,11 @@
 // chunk: a host function that waits until the slot is free, a device-to-host copy into the (page-locked) slot, a host function that
 // publishes the chunk; a receive enqueues: wait until a chunk is published, host-to-device copy out of the slot, release.
 // Every wait gives up after a deadline and poisons the communicator, so a broken test fails instead of hanging the box.
+// TRT_RCCL_STUB_RING = R (default 1): R staging slots per ordered pair, used round robin, so that a sender may be R chunks ahead of
+// its receiver.  With several ranks as THREADS of one process (the 8-rank tests: a GPU box admits six processes) the HIP runtime may
+// run every stream's host functions on one thread, and a sender that blocked there would keep its process's other ranks from
+// publishing: such tests choose slot size and R so that no sender ever has to wait (and keep the receiving root in a process of
+// its own).
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
@@ -66,6 +71,7 @@ struct Shared
     std::atomic<uint64_t> magic;
     std::atomic<int> arrived, failed;
     int world;
+    int ring; // staging slots per ordered pair
     size_t slot_bytes;
     Channel channel[kMaxWorld * kMaxWorld]; // [source * world + destination]
 };
@@ -172,11 +178,12 @@ ncclResult_t transfer(stub_comm *c, bool sending, void *buffer, size_t count, nc
         return ncclSystemError;
     const int source = sending ? c->rank : peer, destination = sending ? peer : c->rank;
     Channel &ch = c->shared->channel[source * c->world + destination];
-    char *slot = c->slots + (size_t)(source * c->world + destination) * c->shared->slot_bytes;
+    const size_t ring = (size_t)c->shared->ring;
+    char *slots = c->slots + (size_t)(source * c->world + destination) * ring * c->shared->slot_bytes; // the pair's `ring` slots
     if (!c->pinned[source * c->world + destination])
-    { // The slot must be page-locked: an asynchronous copy from or to PAGEABLE host memory may touch the host buffer when the
+    { // The slots must be page-locked: an asynchronous copy from or to PAGEABLE host memory may touch the host buffer when the
       // call is made, not when the stream gets there -- before the peer has written the slot, or while it still reads it.
-        if (hipHostRegister(slot, c->shared->slot_bytes, hipHostRegisterDefault) != hipSuccess)
+        if (hipHostRegister(slots, ring * c->shared->slot_bytes, hipHostRegisterDefault) != hipSuccess)
             return ncclUnhandledCudaError;
         c->pinned[source * c->world + destination] = true;
     }
@@ -185,9 +192,10 @@ ncclResult_t transfer(stub_comm *c, bool sending, void *buffer, size_t count, nc
     while (left)
     {
         const size_t chunk = left < c->shared->slot_bytes ? left : c->shared->slot_bytes;
-        // sender: the slot is free once every earlier chunk has been released; receiver: chunk number `mine` is there once
+        // sender: slot (mine mod ring) is free once chunk mine - ring has been released; receiver: chunk number `mine` is there once
         // the sender has published mine + 1 chunks
-        Wait *w = new Wait{c->shared, sending ? &ch.consumed : &ch.produced, sending ? mine : mine + 1};
+        char *slot = slots + (size_t)(mine % ring) * c->shared->slot_bytes;
+        Wait *w = new Wait{c->shared, sending ? &ch.consumed : &ch.produced, sending ? (mine + 1 > ring ? mine + 1 - ring : 0) : mine + 1};
         if (hipLaunchHostFunc(stream, wait_callback, w) != hipSuccess)
             return ncclUnhandledCudaError;
         const hipError_t e = sending ? hipMemcpyAsync(slot, (const char *)buffer + at, chunk, hipMemcpyDeviceToHost, stream)
@@ -222,7 +230,9 @@ extern "C" ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueI
         return ncclInvalidArgument;
     const char *mb = getenv("TRT_RCCL_STUB_SLOT_MB");
     const size_t slot_bytes = (size_t)(mb ? atoi(mb) : 32) << 20;
-    const size_t total = header_bytes() + (size_t)kMaxWorld * kMaxWorld * slot_bytes; // sparse: only touched pages exist
+    const char *rg = getenv("TRT_RCCL_STUB_RING");
+    const int ring = rg && atoi(rg) > 0 ? atoi(rg) : 1;
+    const size_t total = header_bytes() + (size_t)kMaxWorld * kMaxWorld * (size_t)ring * slot_bytes; // sparse: only touched pages exist
     bool creator = true;
     int fd = shm_open(id.internal, O_RDWR | O_CREAT | O_EXCL, 0600);
     if (fd < 0 && errno == EEXIST)
@@ -261,6 +271,7 @@ extern "C" ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueI
     if (creator)
     {
         c->shared->world = world;
+        c->shared->ring = ring;
         c->shared->slot_bytes = slot_bytes;
         c->shared->magic.store(kMagic, std::memory_order_release);
     }
@@ -273,7 +284,7 @@ extern "C" ncclResult_t ncclCommInitRank(ncclComm_t *out, int world, ncclUniqueI
                 return ncclSystemError;
             usleep(1000);
         }
-        if (c->shared->world != world || c->shared->slot_bytes != slot_bytes)
+        if (c->shared->world != world || c->shared->slot_bytes != slot_bytes || c->shared->ring != ring)
             return ncclInvalidArgument;
     }
     // everybody meets here, like ncclCommInitRank; then the name can go (the mappings stay), so nothing is left behind
@@ -303,7 +314,7 @@ extern "C" ncclResult_t ncclCommDestroy(ncclComm_t c)
     const bool failed = c->shared->failed.load() != 0;
     for (int i = 0; i < kMaxWorld * kMaxWorld; i++)
         if (c->pinned[i])
-            (void)hipHostUnregister(c->slots + (size_t)i * c->shared->slot_bytes);
+            (void)hipHostUnregister(c->slots + (size_t)i * (size_t)c->shared->ring * c->shared->slot_bytes);
     munmap((void *)c->shared, c->mapped);
     delete c;
     return failed ? ncclSystemError : ncclSuccess;

@@ -465,6 +465,64 @@ def test_trt_dist_with_several_ranks_on_one_gpu(ctx, tmp_path, world, width, hei
     assert "STAND-IN (TRT_RCCL_LIB)" in outs[0][0], outs[0][0]  # the library says which library it bound in RCCL's place
 
 
+def _write_scene_file(path, scene, cameras):
+    """the input of tests/dist_ranks.c: int32 counts, then doubles (spheres, ground, lights, cameras), then the cubemap's texels"""
+    sky = np.ascontiguousarray(scene.sky, dtype=np.uint8)
+    with open(path, "wb") as fh:
+        np.array([len(scene.spheres), len(scene.dir_lights), len(scene.point_lights), sky.shape[1], len(cameras)], dtype=np.int32).tofile(fh)
+        for a in (scene.spheres, scene.ground, scene.dir_lights, scene.point_lights, np.stack(cameras)):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(fh)
+        sky.tofile(fh)
+
+
+@pytest.mark.parametrize("config", ["c4_2160p", "c5_orbit_f0_f59", "c3_rgb8"])
+def test_the_eight_way_split_of_the_baseline_configs_on_one_gpu(tmp_path, config):
+    """BASELINE configs[3] (3840x2160, 64 spheres, 8 bounces) and configs[4] (256 spheres, 12 bounces, the orbit) NAME 8 GPUs.  No
+    8-GPU node is at hand, but the product path can still be split 8 ways and EXECUTED: eight ranks of trt_dist_* on this box's one
+    GPU -- three processes (a box admits six: rank 0 alone, ranks 1-4 and 5-7 as threads of tests/dist_ranks.c), interleaved 8-row
+    tiles, one gather per frame through the tests' stand-in for RCCL -- and rank 0's assembled frames must carry the hashes the
+    GENUINE reference produced for the whole frames (tests/golden/golden_full.json): 2160p shards with 24.9 MB messages, the
+    patch instantiation of the kernel on 1/8 shards (fewer than 16 M samples each), every one of the 8 receive offsets, three
+    frames in flight with slots re-used.  Correctness only: nothing here says anything about xGMI."""
+    import os
+    import subprocess
+    exe = os.path.join(T.ROOT, "tests", "_build", "dist_ranks")
+    stub = build_rccl_stub()
+    if stub is None or subprocess.run(["make", "-C", T.ROOT, "tests/_build/dist_ranks"], capture_output=True).returncode != 0 or not os.path.exists(exe):
+        pytest.skip("tests/_build/dist_ranks or the RCCL stand-in could not be built")
+    full = T.golden_full()
+    if config == "c4_2160p":
+        cases, rgb8 = [full["c4_2160p_64sph_b8"]] * 4, 0                    # four frames through three slots
+    elif config == "c5_orbit_f0_f59":
+        cases, rgb8 = [full[n] for n in ("c5_1080p_256sph_b12_f0", "c5_1080p_256sph_b12_f59", "c5_1080p_256sph_b12_f0", "c5_1080p_256sph_b12_f59")], 0
+    else:
+        cases, rgb8 = [full[n] for n in ("c3_1080p_64sph_b8_f0", "c3_1080p_64sph_b8_f19", "c3_1080p_64sph_b8_f59", "c3_1080p_64sph_b8")], 1
+    first = cases[0]
+    scene = T.full_scene(first)
+    cams = [np.array(c["camera"], dtype=np.float64) for c in cases]
+    _write_scene_file(tmp_path / "scene.bin", scene, cams)
+    w, h, b = first["width"], first["height"], first["bounce_limit"]
+    # staging: one slot holds a whole shard (2160p: 24.9 MB) and the ring holds every frame of the run, so that no sender ever waits
+    env = dict(os.environ, TRT_RCCL_LIB=stub, TRT_RCCL_STUB_SLOT_MB="32", TRT_RCCL_STUB_RING="4", TRT_RCCL_STUB_DEADLINE="150", GPU_MAX_HW_QUEUES="8")
+    procs = [subprocess.Popen([exe, str(tmp_path / "scene.bin"), ranks, "8", str(tmp_path / "id"), str(w), str(h), str(b), "8", "3", str(rgb8)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for ranks in ("0", "1,2,3,4", "5,6,7")]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=400))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-1200:]
+    got = [line.split()[-1] for line in outs[0][0].splitlines() if line.startswith("frame ")]
+    want = [c["rgb8_fnv" if rgb8 else "fb_fnv"] for c in cases]
+    assert got == want, (got, want)
+    assert all("STAND-IN (TRT_RCCL_LIB)" in err for _, err in outs), outs[0][1][-300:]
+    print("\n" + "".join(err for _, err in outs))
+
+
 def test_bench_two_ranks_through_the_c_abi_on_one_gpu():
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), both ranks on this box's one
     GPU: torch.distributed (gloo) only carries the communicator id and the timing; the frame goes through trt_dist_* over the
