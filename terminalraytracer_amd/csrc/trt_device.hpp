@@ -66,9 +66,52 @@ TRT_DEV double sqrt_exact(double x) // == __builtin_sqrt(x)
 }
 
 // TRT.c:439-450: sqrt of the squared length, then THREE divisions, only when length > 1e-4
+#ifndef TRT_LEAN_UNIT
+#define TRT_LEAN_UNIT 2
+#endif
 TRT_DEV d3 unit(d3 a)
 {
     const double len = sqrt_exact(a.x * a.x + a.y * a.y + a.z * a.z);
+#if TRT_LEAN_MATH && TRT_LEAN_UNIT == 2
+    // Round 4: no branch on the length and no copies.  A vector that is left alone (len <= 1e-4 or NaN) is "divided" by 1.0 --
+    // x 1.0, a zero residual, + 0: the operand's own bits for every finite x -- so the three quotients are formed for every lane.
+    // The short way is taken by the WAVE when, in every active lane, len < 2^300 (false for NaN / inf: then some component is
+    // NaN / inf) and every component is zero or at least 2^-300 in magnitude (|a_k| <= len (1 + 2^-52) bounds them above); one
+    // v_frexp_exp per component and a v_min3 decide that: the exponent of zero is 0, inside the window, and that of a denormal is
+    // below it.  With len >= 1e-4 no quotient, product or residual leaves the normal range.
+    const bool longer = len > 0.0001;
+    const int ex = __builtin_amdgcn_frexp_exp(a.x), ey = __builtin_amdgcn_frexp_exp(a.y), ez = __builtin_amdgcn_frexp_exp(a.z);
+    int lo = ex < ey ? ex : ey;
+    lo = lo < ez ? lo : ez;
+    const bool ok = len < 0x1p300 && lo > -300;
+    if (!__any(!ok))
+    {
+        const double den = longer ? len : 1.0;
+        double r = __builtin_amdgcn_rcp(den);
+        double e = __builtin_fma(-den, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-den, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        double q[3] = {a.x, a.y, a.z};
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+        {
+            const double num = q[k];
+            const double q0 = num * r;
+            const double err = __builtin_fma(-den, q0, num);
+            const double quo = __builtin_fma(err, r, q0);
+            q[k] = __builtin_copysign(quo, num); // v_div_fixup gives the quotient the sign of num/len; matters for +-0 only
+        }
+        return d3{q[0], q[1], q[2]};
+    }
+    if (longer)
+    {
+        a.x /= len;
+        a.y /= len;
+        a.z /= len;
+    }
+    return a;
+#else
     if (len > 0.0001)
     {
 #if TRT_LEAN_MATH
@@ -103,6 +146,7 @@ TRT_DEV d3 unit(d3 a)
         a.z /= len;
     }
     return a;
+#endif
 }
 
 // the compiler's own expansions, for trt_selftest_unit

@@ -98,6 +98,24 @@ KERNEL(sweep_chain_x11, DCH, REP8(X_CHAIN), SCH)
 KERNEL(alignbit, DI, REP8(X_ALIGN), SI)
 KERNEL(sub_f32, D32, REP8(X_SUB32), S32)
 KERNEL(cndmask_sgpr, DI, REP8(X_CNDS), SI)
+// round 4: what the range checks and copies of unit() are made of
+#define X_FREXP(i) asm volatile("v_frexp_exp_i32_f64 %0, %1" : "=v"(e##i) : "v"(a##i));
+#define DFX double a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7; int e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0, e6 = 0, e7 = 0;
+#define SFX if (e0 + e1 + e2 + e3 + e4 + e5 + e6 + e7 == 12345) out[0] = 1;
+KERNEL(frexp_exp_f64, DFX, REP8(X_FREXP), SFX)
+#define X_MOV64(i) asm volatile("v_mov_b64 %0, %1" : "+v"(a##i) : "v"(b));
+KERNEL(mov_b64, D64, REP8(X_MOV64), S64)
+#define X_MIN3(i) asm volatile("v_min3_i32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+KERNEL(min3_i32, DI, REP8(X_MIN3), SI)
+#define X_BFI(i) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a##i) : "v"(b), "v"(c));
+KERNEL(bfi_b32, DI, REP8(X_BFI), SI)
+#define X_CLASS64(i) asm volatile("v_cmp_class_f64 vcc, %0, %1" ::"v"(a##i), "v"(k) : "vcc");
+#define DCL double a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7; unsigned k = 0x1f8;
+KERNEL(cmp_class_f64, DCL, REP8(X_CLASS64), S64)
+#define X_ADDU(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+KERNEL(add_u32, DI, REP8(X_ADDU), SI)
+#define X_CMPU(i) asm volatile("v_cmp_gt_u32 vcc, %0, %1" ::"v"(a##i), "v"(b) : "vcc");
+KERNEL(cmp_gt_u32, DI, REP8(X_CMPU), SI)
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 #define DPK f2 p0 = {(float)seed, 1.f}, p1 = p0 + 1.f, p2 = p0 + 2.f, p3 = p0 + 3.f, p4 = p0 + 4.f, p5 = p0 + 5.f, p6 = p0 + 6.f, p7 = p0 + 7.f, pb = p0 * 0.5f, pc = {1.0000001f, 0.9999999f};
@@ -139,7 +157,9 @@ int main()
                     {"v_div_fixup_f64", k_div_fixup_f64}, {"v_ldexp_f64", k_ldexp_f64}, {"v_cmp_lt_f64", k_cmp_f64},
                     {"v_cvt_f32_f64", k_cvt_f32_f64}, {"v_fma_f32", k_fma_f32}, {"v_fmac_f32", k_fmac_f32},
                     {"v_cmp_lt_f32 vcc", k_cmp_f32_vcc}, {"v_cmp_lt_f32 sgpr", k_cmp_f32_sgpr}, {"v_cndmask_b32", k_cndmask_b32},
-                    {"v_mov_b32", k_mov_b32}, {"v_or3_b32", k_or3_b32}, {"v_addc_co_u32", k_addc_u32}, {"v_readlane_b32", k_readlane}, {"v_fmac_f32 s,v", k_fmac_f32_sgpr}, {"v_fmac_f32 s2x,v", k_fmac_f32_sgpr_var}, {"v_mul_f32 s,v", k_mul_f32_sgpr}, {"v_fma_f32 s,v,-v", k_fma_f32_sgpr}, {"v_subrev_f32 s,v", k_subrev_f32_sgpr}, {"v_or_b32", k_or_b32}, {"sweep chain (11)", k_sweep_chain_x11}, {"v_alignbit_b32", k_alignbit}, {"v_sub_f32", k_sub_f32}, {"v_cndmask_b32 sgpr", k_cndmask_sgpr}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_mfma_f32_32x32x2", k_mfma_32x32x2_f32}};
+                    {"v_mov_b32", k_mov_b32}, {"v_or3_b32", k_or3_b32}, {"v_addc_co_u32", k_addc_u32}, {"v_readlane_b32", k_readlane}, {"v_fmac_f32 s,v", k_fmac_f32_sgpr}, {"v_fmac_f32 s2x,v", k_fmac_f32_sgpr_var}, {"v_mul_f32 s,v", k_mul_f32_sgpr}, {"v_fma_f32 s,v,-v", k_fma_f32_sgpr}, {"v_subrev_f32 s,v", k_subrev_f32_sgpr}, {"v_or_b32", k_or_b32}, {"sweep chain (11)", k_sweep_chain_x11}, {"v_alignbit_b32", k_alignbit}, {"v_sub_f32", k_sub_f32}, {"v_cndmask_b32 sgpr", k_cndmask_sgpr}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_mfma_f32_32x32x2", k_mfma_32x32x2_f32},
+                    {"v_frexp_exp_i32_f64", k_frexp_exp_f64}, {"v_mov_b64", k_mov_b64}, {"v_min3_i32", k_min3_i32}, {"v_bfi_b32", k_bfi_b32},
+                    {"v_cmp_class_f64", k_cmp_class_f64}, {"v_add_u32", k_add_u32}, {"v_cmp_gt_u32", k_cmp_gt_u32}};
     unsigned long long *d;
     hipMalloc(&d, 1 << 20);
     printf("%-20s %10s %10s %10s %10s   (cycles per wave-instruction per SIMD = wave cycles / instrs * waves... see columns)\n", "instruction",
