@@ -181,8 +181,15 @@ TRT_HD int trt_pointgrid_cell(const trt_pointgrid *G, double ox, double oy, doub
     float cu = __builtin_fmaf(pu * inv, G->half_g, G->half_g), cv = __builtin_fmaf(pv * inv, G->half_g, G->half_g);
     cu = __builtin_fminf(__builtin_fmaxf(cu, 0.0f), G->g_max);
     cv = __builtin_fminf(__builtin_fmaxf(cv, 0.0f), G->g_max);
-    /* shell of the origin's distance from the light; min(x, s_max) with x first: NaN -> the outermost shell, which holds everything */
-    const float cs = __builtin_fminf(__builtin_sqrtf(r2) * G->inv_shell, G->s_max);
+    /* shell of the origin's distance from the light; min(x, s_max) with x first: NaN -> the outermost shell, which holds everything.
+     * On the device the square root is the bare v_sqrt_f32 (1 ulp; no denormal scaling: r2 > 0 is far from denormal for any origin
+     * that is not `far`): the builder's growth of every sphere by delta and of every shell by 0.01 shell covers an ulp many times */
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float dist = __builtin_amdgcn_sqrtf(r2);
+#else
+    const float dist = __builtin_sqrtf(r2);
+#endif
+    const float cs = __builtin_fminf(dist * G->inv_shell, G->s_max);
     return (((int)cs * 6 + face) * G->g + (int)cv) * G->g + (int)cu;
 }
 

@@ -405,23 +405,29 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         }
     }
     TRT_TRACE_STAMP(2); // exact tests
-    // ground plane (TRT.c:831-853)
-    if (active && !(ANY_HIT && best.i >= 0))
+    // ground plane (TRT.c:831-853; ray_intersects_plane TRT.c:677-695).  One wave-level decision, then straight-line code with
+    // selects: a ray can only hit if |d.n| > 1e-5 and numerator and denominator of t have the same sign (opposite signs: t <= 0,
+    // whatever the quotient's digits are), so a wave whose rays all head away from the plane skips the division.
     {
-        d3 p;
-        if (hit_plane(o, d, gp, gn, p))
+        const double denom = dot(d, gn), num = dot(sub(gp, o), gn);
+        const bool maybe = active && !(ANY_HIT && best.i >= 0) && __builtin_fabs(denom) > 0.00001 &&
+                           (long long)(__builtin_bit_cast(unsigned long long, num) ^ __builtin_bit_cast(unsigned long long, denom)) >= 0;
+        if (__any(maybe))
         {
+            const double t = num / denom;
+            const bool hit = maybe && t > 0.00001;
             if (ANY_HIT)
-                best.i = n; // nothing closer can matter: any hit blocks the light
+                best.i = hit ? n : best.i; // nothing closer can matter: any hit blocks the light
             else
             {
+                const d3 p = d3{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};
                 const double d2 = dist2(o, p);
-                if (d2 < best.d2)
-                {
-                    best.d2 = d2;
-                    best.p = p;
-                    best.i = n;
-                }
+                const bool closer = hit && d2 < best.d2;
+                best.d2 = closer ? d2 : best.d2;
+                best.p.x = closer ? p.x : best.p.x;
+                best.p.y = closer ? p.y : best.p.y;
+                best.p.z = closer ? p.z : best.p.z;
+                best.i = closer ? n : best.i;
             }
         }
     }
