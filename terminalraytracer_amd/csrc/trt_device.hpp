@@ -46,9 +46,12 @@ TRT_DEV unsigned lo32(double x) { return (unsigned)__builtin_bit_cast(unsigned l
 // positive, finite, biased exponent in [723, 1323): 2^-300 <= x < 2^300
 TRT_DEV bool mid_range(double x) { return hi32(x) - (723u << 20) < (600u << 20); }
 
+#ifndef TRT_LEAN_SQRT
+#define TRT_LEAN_SQRT 1
+#endif
 TRT_DEV double sqrt_exact(double x) // == __builtin_sqrt(x)
 {
-#if TRT_LEAN_MATH
+#if TRT_LEAN_MATH && TRT_LEAN_SQRT
     if (!__any(!mid_range(x)))
     { // the steps of the compiler's expansion between its scaling and its 0/inf select
         const double y = __builtin_amdgcn_rsq(x);
