@@ -236,10 +236,9 @@ TRT_DEV int frame_row_of_magic(const FrameView &f, unsigned local_row)
 {
     unsigned t = __umulhi(local_row, f.tile_magic);
     int within = (int)(local_row - t * (unsigned)f.tile_rows);
-    if (within < 0)
-        t--, within += f.tile_rows;
-    else if (within >= f.tile_rows)
-        t++, within -= f.tile_rows;
+    const int under = within < 0, over = within >= f.tile_rows;
+    t += (unsigned)(over - under);
+    within += (under - over) * f.tile_rows;
     return (f.tile_first + (int)t * f.tile_step) * f.tile_rows + within;
 }
 

@@ -1007,21 +1007,25 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
                     if (alive)
                     {
                         // unit -> (pixel, k) -> (row, column) by multiply-high with min(ceil(2^32/x), 2^32-1): off by at most one
+                        // either way; the correction is two selects each, not branches (three nested exec regions per lane before)
                         unsigned pixel = __umulhi(mine, f.spp_magic);
                         int k = (int)(mine - pixel * (unsigned)f.spp);
-                        if (k < 0)
-                            pixel--, k += f.spp;
-                        else if (k >= f.spp)
-                            pixel++, k -= f.spp;
+                        {
+                            const int under = k < 0, over = k >= f.spp;
+                            pixel += (unsigned)(over - under);
+                            k += (under - over) * f.spp;
+                        }
                         slot_id = (unsigned)k * pixels_here + pixel; // sample-major scratch: the reduction streams it
                         unsigned row = __umulhi(pixel, f.width_magic);
                         int col = (int)(pixel - row * (unsigned)f.width);
-                        if (col < 0)
-                            row--, col += f.width;
-                        else if (col >= f.width)
-                            row++, col -= f.width;
+                        {
+                            const int under = col < 0, over = col >= f.width;
+                            row += (unsigned)(over - under);
+                            col += (under - over) * f.width;
+                        }
                         const double sx = f.col_x[col] + L.jit[k];
-                        const double sy = f.row_y[frame_row_of_magic(f, row)] + L.jit[f.spp + k];
+                        // rows dealt from tile 0 with step 1 (a whole frame, a one-rank shard): the local row IS the frame row
+                        const double sy = f.row_y[f.tile_first == 0 && f.tile_step == 1 ? (int)row : frame_row_of_magic(f, row)] + L.jit[f.spp + k];
                         d3 dir = d3{0.0, 0.0, 0.0};
                         dir = add(dir, scale(load3(L.cam + 0), sx));
                         dir = add(dir, scale(load3(L.cam + 3), sy));

@@ -95,6 +95,8 @@ with hip.Context(0) as ctx:
             w, h, spp = min(w, 96), min(h, 54), int(rng.choice([1, 3]))
             ctx.set_path_patches(-1 if seed % 3 else int(rng.choice([1, 3, 4])))
             ctx.set_path_grids(64, 32 if seed % 3 else 8)
+        if seed % 2 == 0:  # round 4: the light tables' depth coordinate (slabs along a directional light, shells about a point light)
+            ctx.set_light_slabs(int(rng.choice([1, 3, 16, 64])), int(rng.choice([1, 5, 16, 64])))
         if mode == "compact" and seed % 3 == 0:
             b = 1  # every hit ends its sample: the ring is flushed in every round
         if patches:
