@@ -482,25 +482,20 @@ TRT_DEV void point_light_search(const LdsImage &L, int n, d3 o, d3 d, bool activ
             count = blocks ? 0 : count;
         }
     }
-    // the ground (TRT.c:677-695) for the lanes that are not dark yet
-    if (__any(active && !dark))
+    // the ground (TRT.c:677-695) for the lanes that are not dark yet: one wave-level decision, as in trace() -- a ray can only
+    // hit if |d.n| > 1e-5 and numerator and denominator of t have the same sign (opposite signs: t <= 0)
     {
-        const double denom = dot(d, gn);
-        if (active && !dark && __builtin_fabs(denom) > 0.00001)
+        const double denom = dot(d, gn), num = dot(sub(gp, o), gn);
+        const bool maybe = active && !dark && __builtin_fabs(denom) > 0.00001 &&
+                           (long long)(__builtin_bit_cast(unsigned long long, num) ^ __builtin_bit_cast(unsigned long long, denom)) >= 0;
+        if (__any(maybe))
         {
-            const double num = dot(sub(gp, o), gn);
-            // opposite signs: t <= 0, a miss (as in hit_plane: a wave whose rays all head away from the plane skips the division)
-            if ((long long)(__builtin_bit_cast(unsigned long long, num) ^ __builtin_bit_cast(unsigned long long, denom)) >= 0)
-            {
-                const double t = num / denom;
-                if (t > 0.00001)
-                {
-                    const double qq = (t * t) * (4.0 * a) * a; // q = 2 a t
-                    const bool blocks = qq * TRT_SHADOW_K1 <= lo;
-                    dark = blocks;
-                    unsure = unsure || (!blocks && !(qq >= hi));
-                }
-            }
+            const double t = num / denom;
+            const bool hit = maybe && t > 0.00001;
+            const double qq = (t * t) * (4.0 * a) * a; // q = 2 a t
+            const bool blocks = hit && qq * TRT_SHADOW_K1 <= lo;
+            dark = dark || blocks;
+            unsure = unsure || (hit && !blocks && !(qq >= hi));
         }
     }
     unsure = unsure && !dark;
