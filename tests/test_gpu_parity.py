@@ -108,6 +108,15 @@ def test_production_stages_match_reference_single_ray_vectors(ctx, grids):
             # a WRONG family must not matter either: the membership test sends such rays to the sweep
             wrong = np.roll(codes, 7)
             _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], wrong), want)
+            # nor must codes the tables have no family for (the numbering of an older header, a patch number beyond the
+            # patches, a sphere beyond the scene, garbage): the library maps them to "no family" before the kernel sees them
+            n_s = len(scene.spheres)
+            garbage = np.array(codes, dtype=np.int64)
+            garbage[0::4] = 2 + n_s + ((np.arange(len(garbage[0::4])) % max(n_s, 1)) << 7 | 127)  # patch 127 of a sphere
+            garbage[1::4] = 2 + n_s + ((n_s + 5) << 7)                                          # a sphere beyond the scene
+            garbage[2::4] = 2 ** 31 - 1
+            garbage[3::4] = -7
+            _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], garbage.astype(np.int32)), want)
             _same_probe(ctx.probe_rays(fam[tag + "/rays"]), want)  # and the reference-order kernel's probe
     finally:
         ctx.set_path_patches(-1)
@@ -1320,3 +1329,26 @@ def test_a_scene_that_changes_with_every_call_of_the_drop_in_entry(ctx):
         assert np.array_equal(bits(got), bits(want))
     finally:
         hip._check(lib.trt_set_scene_policy(2, 3))
+
+
+def test_the_automatic_patch_policy_steps_down_instead_of_failing(ctx):
+    """24 patches per sphere are the default from 128 spheres up; with a finer direction grid than the default the tables
+    they ask for do not fit (256 spheres at 128 cells per side: 1.2e9 cells).  The automatic policy then steps down (2 -> 1 -> 0
+    cells per side of the origin's cube map) until cells and pool fit its budget (4 GB); an m asked for by number is taken as it is."""
+    scene = S.synth_scene(256, T.sky("synth"), T.bench_camera(64, 36))
+    want, _ = T.oracle_render(scene, 64, 36, 6, 4)
+    c = hip.Context(0)
+    try:
+        c.set_path_grids(64, 128)
+        c.set_scene(scene)
+        assert c.path_patches() == (1, 6), c.path_patches()       # 3e8 cells instead of 1.2e9
+        assert c.scene_info()["table_bytes"] < 5 << 30
+        got = c.render_host(scene.camera, hip.RowSet.whole(64, 36), 6, 4)
+        assert np.array_equal(bits(got), bits(want))
+        c.set_path_grids(64, 32)
+        assert c.path_patches() == (2, 24)                          # the default grid: the default patches
+        c.set_path_grids(64, 48)
+        c.set_path_patches(3)                                       # asked for by number: taken as it is (54 patches, 3.8e8 cells)
+        assert c.path_patches() == (3, 54)
+    finally:
+        c.close()
