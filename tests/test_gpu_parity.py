@@ -1296,6 +1296,7 @@ def test_a_scene_that_changes_with_every_call_of_the_drop_in_entry(ctx):
     import time
     scene = S.synth_scene(256, T.sky("synth"), T.bench_camera(96, 54))
     lib = hip.lib()
+    hip._check(lib.trt_shutdown())  # a fresh default context: earlier tests have handed the drop-in entries other scenes
     hip._check(lib.trt_set_scene_policy(2, 3))
     try:
         took, moving = [], []
