@@ -1177,12 +1177,13 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         const int h_mat = hit.mat;
         bool end_sample = false;
         double weight_sum_new = weight_sum + weight; // TRT.c:1034
+        uint32_t sky_t = 0;
         if (path_sky)
-        { // TRT.c:858-867, :1044-1048: colour = texel, the sample ends here
+        { // TRT.c:858-867, :1044-1048: colour = texel, the sample ends here.  The texel is only LOADED here: it is a dependent read
+          // from global memory, and what uses it (the sample's colour) is not needed before the END of the round, behind the other
+          // lanes' shadow stages
             TRT_FRESH_ARGS;
-            const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f);
-            const d3 color = d3{L.b255[t & 0xFF], L.b255[(t >> 8) & 0xFF], L.b255[(t >> 16) & 0xFF]};
-            sample = add(sample, scale(color, weight));
+            sky_t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f);
             end_sample = true;
         }
         d3 lit;
@@ -1262,6 +1263,11 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
             weight_sum_new = weight_sum; // nothing was contributed
             if (!(bounces < f.bounce_limit))
                 end_sample = true;
+        }
+        if (path_sky)
+        { // TRT.c:866, :1035-1051: colour = texel / 255, scaled by the sample's weight
+            const d3 color = d3{L.b255[sky_t & 0xFF], L.b255[(sky_t >> 8) & 0xFF], L.b255[(sky_t >> 16) & 0xFF]};
+            sample = add(sample, scale(color, weight));
         }
         if (__any(end_sample))
         { // TRT.c:1061: the sample's colour, normalised by the weights it gathered
