@@ -279,6 +279,12 @@ int trt_selftest_div_sqrt(trt_context *ctx, const double *a, const double *b, si
  * records {x, y, z, w}: out = {unit(x,y,z), sqrt(w)}.  The two outputs must be identical bit for bit. */
 int trt_selftest_unit(trt_context *ctx, const double *xyzw, size_t n, double *fast, double *reference);
 
+/* The candidate tables over cube maps (point lights, ray families, surface patches) take face and face coordinates of a
+ * direction from gfx9's v_cubeid / v_cubesc / v_cubetc / v_cubema; the host-side builders and checkers use a C restatement of the
+ * four instructions (csrc/trt_lightgrid.h, trt_cube_lookup).  n directions {x, y, z} in, {face, sc, tc, 2 * major} per direction out:
+ * as the device computes them and as the host restatement does.  The two must agree bit for bit. */
+int trt_selftest_cube(trt_context *ctx, const float *xyz, size_t n, float *device_out, float *host_out);
+
 /* Single-ray probe for tests: closest hit of TRT.c:793 for n rays (host arrays): obj[n],
  * point[3n], normal[3n], material[5n] (colour, reflectivity, specularity); lit[3n] = colour after
  * the lighting of TRT.c:894 for hits. */

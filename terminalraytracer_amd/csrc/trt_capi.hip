@@ -1851,6 +1851,46 @@ extern "C" int trt_selftest_unit(trt_context *ctx, const double *xyzw, size_t n,
     return TRT_OK;
 }
 
+namespace
+{
+// trt_cube_lookup as the DEVICE evaluates it (v_cubeid / v_cubesc / v_cubetc / v_cubema): {face, sc, tc, ma2} per direction
+__global__ void cube_selftest_kernel(const float *xyz, long n, float *out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    int face;
+    float sc, tc, ma2;
+    trt_cube_lookup(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &face, &sc, &tc, &ma2);
+    out[4 * i] = (float)face, out[4 * i + 1] = sc, out[4 * i + 2] = tc, out[4 * i + 3] = ma2;
+}
+} // namespace
+
+extern "C" int trt_selftest_cube(trt_context *ctx, const float *xyz, size_t n, float *device_out, float *host_out)
+{
+    if (!ctx || !xyz || !device_out || !host_out)
+        return fail(TRT_ERR_ARGUMENT, "NULL argument");
+    if (n == 0)
+        return TRT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceBuffer<float> buf;
+    HIP_TRY(buf.reserve(7 * n));
+    HIP_TRY(hipMemcpy(buf.ptr, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(cube_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)buf.ptr, (long)n, buf.ptr + 3 * n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(device_out, buf.ptr + 3 * n, 4 * n * sizeof(float), hipMemcpyDeviceToHost));
+    buf.release();
+    for (size_t i = 0; i < n; i++)
+    { // the same header compiled for the host: the C restatement of the four instructions
+        int face;
+        float sc, tc, ma2;
+        trt_cube_lookup(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &face, &sc, &tc, &ma2);
+        host_out[4 * i] = (float)face, host_out[4 * i + 1] = sc, host_out[4 * i + 2] = tc, host_out[4 * i + 3] = ma2;
+    }
+    return TRT_OK;
+}
+
 extern "C" int trt_probe_rays(trt_context *ctx, const Ray *rays, size_t n, int *obj, double *point, double *normal,
                               double *material, double *lit)
 {

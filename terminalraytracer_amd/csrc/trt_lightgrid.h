@@ -141,6 +141,50 @@ TRT_HD void trt_point_shadow_bounds(const trt_pointgrid *G, double light_d2, dou
     *hi = ok ? h : __builtin_inf();
 }
 
+/* Cube-map face and face coordinates of a direction (x, y, z), AS gfx9's V_CUBEID / V_CUBESC / V_CUBETC / V_CUBEMA DEFINE THEM
+ * (four instructions on the device; the C below restates the ISA manual's pseudo-code, ties included, and a GPU test compares the
+ * two): the major axis is z if |z| >= |x| and |z| >= |y|, else y if |y| >= |x|, else x;
+ *     face   +X 0   -X 1   +Y 2   -Y 3   +Z 4   -Z 5
+ *     sc     -z     +z     +x     +x     +x     -x
+ *     tc     -y     -y     +z     -z     -y     -y          *ma2 = 2 x the major component (signed)
+ * so that the direction is proportional to trt_face_direction(face, sc / |major|, tc / |major|).  Every table over a cube map
+ * (point lights, ray families, the patches of a sphere's surface) uses these face frames, builders and look-ups alike. */
+TRT_HD void trt_cube_lookup(float x, float y, float z, int *face, float *sc, float *tc, float *ma2)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    *face = (int)__builtin_amdgcn_cubeid(x, y, z);
+    *sc = __builtin_amdgcn_cubesc(x, y, z);
+    *tc = __builtin_amdgcn_cubetc(x, y, z);
+    *ma2 = __builtin_amdgcn_cubema(x, y, z);
+#else
+    /* the instructions COMPARE and DOUBLE with FP32 denormals flushed to zero, and pass sc and tc through as they are (observed:
+     * tests/test_gpu_parity.py::test_the_cube_instructions_equal_their_c_restatement) */
+    const float fx = __builtin_fabsf(x) < 1.17549435e-38f ? 0.0f * x : x, fy = __builtin_fabsf(y) < 1.17549435e-38f ? 0.0f * y : y,
+                fz = __builtin_fabsf(z) < 1.17549435e-38f ? 0.0f * z : z;
+    const float ax = __builtin_fabsf(fx), ay = __builtin_fabsf(fy), az = __builtin_fabsf(fz);
+    if (az >= ax && az >= ay)
+        *face = fz < 0.0f ? 5 : 4, *sc = fz < 0.0f ? -x : x, *tc = -y, *ma2 = fz * 2.0f;
+    else if (ay >= ax)
+        *face = fy < 0.0f ? 3 : 2, *sc = x, *tc = fy < 0.0f ? -z : z, *ma2 = fy * 2.0f;
+    else
+        *face = fx < 0.0f ? 1 : 0, *sc = fx < 0.0f ? z : -z, *tc = -y, *ma2 = fx * 2.0f;
+#endif
+}
+
+/* direction of the point (u, v) of a cube-map face, major component +-1, in world axes: the frame of trt_cube_lookup */
+TRT_HD void trt_face_direction(int face, double u, double v, double out[3])
+{
+    switch (face)
+    {
+    case 0: out[0] = 1.0, out[1] = -v, out[2] = -u; break;
+    case 1: out[0] = -1.0, out[1] = -v, out[2] = u; break;
+    case 2: out[0] = u, out[1] = 1.0, out[2] = v; break;
+    case 3: out[0] = u, out[1] = -1.0, out[2] = -v; break;
+    case 4: out[0] = u, out[1] = -v, out[2] = 1.0; break;
+    default: out[0] = -u, out[1] = -v, out[2] = -1.0; break;
+    }
+}
+
 /* cell index of the shadow ray that starts at o; *far != 0: do not use the grid for this ray */
 TRT_HD int trt_dirgrid_cell(const trt_dirgrid *G, double ox, double oy, double oz, int *far)
 {
@@ -162,21 +206,13 @@ TRT_HD int trt_pointgrid_cell(const trt_pointgrid *G, double ox, double oy, doub
     const float w[3] = {(float)(ox - G->l[0]), (float)(oy - G->l[1]), (float)(oz - G->l[2])};
     const float r2 = __builtin_fmaf(w[2], w[2], __builtin_fmaf(w[1], w[1], w[0] * w[0]));
     *far = !(r2 <= G->rg2) || !(r2 > 0.0f);
-    const float ax = __builtin_fabsf(w[0]), ay = __builtin_fabsf(w[1]), az = __builtin_fabsf(w[2]);
-    /* major axis k; u along axis k+1, v along axis k+2 (cyclic) */
-    float major, pu, pv;
     int face;
-    if (ax >= ay && ax >= az)
-        major = w[0], pu = w[1], pv = w[2], face = 0;
-    else if (ay >= az)
-        major = w[1], pu = w[2], pv = w[0], face = 2;
-    else
-        major = w[2], pu = w[0], pv = w[1], face = 4;
-    face += major < 0.0f;
+    float pu, pv, ma2;
+    trt_cube_lookup(w[0], w[1], w[2], &face, &pu, &pv, &ma2);
 #if defined(__HIP_DEVICE_COMPILE__)
-    const float inv = __builtin_amdgcn_rcpf(__builtin_fabsf(major));
+    const float inv = __builtin_amdgcn_rcpf(0.5f * __builtin_fabsf(ma2));
 #else
-    const float inv = 1.0f / __builtin_fabsf(major);
+    const float inv = 1.0f / (0.5f * __builtin_fabsf(ma2));
 #endif
     float cu = __builtin_fmaf(pu * inv, G->half_g, G->half_g), cv = __builtin_fmaf(pv * inv, G->half_g, G->half_g);
     cu = __builtin_fminf(__builtin_fmaxf(cu, 0.0f), G->g_max);
@@ -255,12 +291,17 @@ TRT_HD int trt_pointgrid_reaches(const trt_pointgrid_cone *s, int face, int c, i
 {
     if (s->everywhere != 0.0)
         return 1;
-    const int k = face >> 1;
-    const double sg = (face & 1) ? -1.0 : 1.0;
-    /* the cone's axis in the face's frame: (u, v, major), major > 0 on the face */
-    const double au = k == 0 ? s->a[1] : (k == 1 ? s->a[2] : s->a[0]); /* axis (k+1) % 3 */
-    const double av = k == 0 ? s->a[2] : (k == 1 ? s->a[0] : s->a[1]); /* axis (k+2) % 3 */
-    const double am = sg * (k == 0 ? s->a[0] : (k == 1 ? s->a[1] : s->a[2]));
+    /* the cone's axis in the face's frame (trt_cube_lookup / trt_face_direction): (u, v, major), major > 0 on the face */
+    double au, av, am;
+    switch (face)
+    {
+    case 0: au = -s->a[2], av = -s->a[1], am = s->a[0]; break;
+    case 1: au = s->a[2], av = -s->a[1], am = -s->a[0]; break;
+    case 2: au = s->a[0], av = s->a[2], am = s->a[1]; break;
+    case 3: au = s->a[0], av = -s->a[2], am = -s->a[1]; break;
+    case 4: au = s->a[0], av = -s->a[1], am = s->a[2]; break;
+    default: au = -s->a[0], av = -s->a[1], am = -s->a[2]; break;
+    }
     const double step = 2.0 / (double)g;
     const double u0 = c == 0 ? -TRT_POINTGRID_EDGE : -1.0 + ((double)c - 0.01) * step;
     const double u1 = c == g - 1 ? TRT_POINTGRID_EDGE : -1.0 + ((double)c + 1.01) * step;

@@ -103,23 +103,16 @@ static inline void trt_eye_families(const double eye[3], const double *ground /*
     }
 }
 
-/* cell of direction (x, y, z) (any length > 0) in a cube map of 6 x g x g cells: the look-up of trt_pointgrid_cell */
+/* cell of direction (x, y, z) (any length > 0) in a cube map of 6 x g x g cells: the look-up of trt_pointgrid_cell (trt_cube_lookup) */
 TRT_HD int trt_cubemap_cell(float x, float y, float z, float half_g, float g_max, int g)
 {
-    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
-    float major, pu, pv;
     int face;
-    if (ax >= ay && ax >= az)
-        major = x, pu = y, pv = z, face = 0;
-    else if (ay >= az)
-        major = y, pu = z, pv = x, face = 2;
-    else
-        major = z, pu = x, pv = y, face = 4;
-    face += major < 0.0f;
+    float pu, pv, ma2;
+    trt_cube_lookup(x, y, z, &face, &pu, &pv, &ma2);
 #if defined(__HIP_DEVICE_COMPILE__)
-    const float inv = __builtin_amdgcn_rcpf(__builtin_fabsf(major));
+    const float inv = __builtin_amdgcn_rcpf(0.5f * __builtin_fabsf(ma2));
 #else
-    const float inv = 1.0f / __builtin_fabsf(major);
+    const float inv = 1.0f / (0.5f * __builtin_fabsf(ma2));
 #endif
     float cu = __builtin_fmaf(pu * inv, half_g, half_g), cv = __builtin_fmaf(pv * inv, half_g, half_g);
     cu = __builtin_fminf(__builtin_fmaxf(cu, 0.0f), g_max);
@@ -154,15 +147,6 @@ typedef struct
     int count; /* P: 1, or 6 m^2 */
     double rec[TRT_PATCH_MAX][4]; /* per patch: apex offset t in units of the radius (3), membership radius rho in units of the radius */
 } trt_patchset;
-
-/* direction (u, v, 1) of a cube-map face in world axes: the frame of trt_cubemap_cell / trt_pointgrid_reaches */
-static inline void trt_face_direction(int face, double u, double v, double out[3])
-{
-    const int k = face >> 1;
-    out[k] = (face & 1) ? -1.0 : 1.0;
-    out[(k + 1) % 3] = u;
-    out[(k + 2) % 3] = v;
-}
 
 static inline void trt_patchset_init(trt_patchset *P, int m)
 {

@@ -91,6 +91,7 @@ SYMBOLS = {
     "trt_set_refraction": (_I, [_VP, _VP, _I]),
     "trt_reserve_cus": (_I, [_VP, _I]),
     "trt_get_stream": (_I, [_VP, C.POINTER(C.c_void_p)]),
+    "trt_selftest_cube": (_I, [_VP, _VP, C.c_size_t, _VP, _VP]),
     "trt_selftest_unit": (_I, [_VP, _VP, C.c_size_t, _VP, _VP]),
     "trt_read_light_grid": (C.c_long, [_VP, _I, _I, _VP, C.c_size_t]),
     "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
@@ -299,6 +300,13 @@ class Context:
         fast, ref = np.zeros_like(v), np.zeros_like(v)
         _check(lib().trt_selftest_unit(self._h, v.ctypes.data, v.shape[0], fast.ctypes.data, ref.ctypes.data))
         return fast, ref
+
+    def selftest_cube(self, xyz):
+        """(device, host): {face, sc, tc, 2 * major} of directions by v_cubeid / sc / tc / ma and by their C restatement"""
+        v = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        dev, host = np.zeros((v.shape[0], 4), dtype=np.float32), np.zeros((v.shape[0], 4), dtype=np.float32)
+        _check(lib().trt_selftest_cube(self._h, v.ctypes.data, v.shape[0], dev.ctypes.data, host.ctypes.data))
+        return dev, host
 
     def read_light_grid(self, point_light, index, words):
         """one light's device-built candidate table as uint64 words (trt_read_light_grid)"""

@@ -1353,3 +1353,28 @@ def test_the_automatic_patch_policy_steps_down_instead_of_failing(ctx):
         assert c.path_patches() == (3, 54)
     finally:
         c.close()
+
+
+def test_the_cube_instructions_equal_their_c_restatement(ctx):
+    """Since round 4 the cube-map look-ups of the candidate tables are gfx9's v_cubeid / v_cubesc / v_cubetc / v_cubema on the device
+    and a C restatement of the ISA manual's pseudo-code on the host (builders, conservativeness checkers: csrc/trt_lightgrid.h,
+    trt_cube_lookup).  Face, both face coordinates and the doubled major component must agree bit for bit: random directions of all
+    magnitudes, every kind of tie (|x| = |y|, |y| = |z|, all three, with every sign pattern), zeros of both signs, denormals, inf."""
+    rng = np.random.default_rng(41)
+    v = (rng.normal(size=(400000, 3)) * 10.0 ** rng.uniform(-30, 30, (400000, 1))).astype(np.float32)
+    ties = []
+    for a in (1.0, 0.3, 1e-20, 3e15, 0.0):
+        for b in (a, a * 0.5, 0.0):
+            for sx in (1, -1):
+                for sy in (1, -1):
+                    for sz in (1, -1):
+                        ties += [[sx * a, sy * a, sz * b], [sx * a, sy * b, sz * a], [sx * b, sy * a, sz * a], [sx * a, sy * a, sz * a]]
+    special = [[0.0, 0.0, 0.0], [-0.0, 0.0, -0.0], [1e-42, 2e-42, -1e-42], [np.inf, 1.0, 2.0], [1.0, -np.inf, np.inf], [3.0, 3.0, -3.0],
+               [1.0, 1e-40, 0.5], [-1e-39, 2.0, 3e-41], [1e-40, -1e-41, -7.0], [2e-38, 1e-39, -1e-38], [-1e-40, 1e-38, 0.0]]  # denormals among normals
+    v = np.concatenate([v, np.array(ties, dtype=np.float32), np.array(special, dtype=np.float32)])
+    dev, host = ctx.selftest_cube(v)
+    null = (np.abs(v) < 1.1754944e-38).all(axis=1)  # no direction (denormals count as zeros): the hardware goes by sign BITS; such a vector is
+    assert np.isin(dev[null, 0], (4.0, 5.0)).all() and (dev[null, 3] == 0).all()    # never looked up (|o - l|^2 > 0 / unit direction)
+    same = dev.view(np.uint32)[~null] == host.view(np.uint32)[~null]
+    bad = (~same).any(axis=1)
+    assert same.all(), (int(bad.sum()), v[~null][bad][:5], dev[~null][bad][:5], host[~null][bad][:5])
