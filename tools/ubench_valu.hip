@@ -116,6 +116,19 @@ KERNEL(cmp_class_f64, DCL, REP8(X_CLASS64), S64)
 KERNEL(add_u32, DI, REP8(X_ADDU), SI)
 #define X_CMPU(i) asm volatile("v_cmp_gt_u32 vcc, %0, %1" ::"v"(a##i), "v"(b) : "vcc");
 KERNEL(cmp_gt_u32, DI, REP8(X_CMPU), SI)
+// integer multiplies: what index arithmetic is made of
+#define X_MULLO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+KERNEL(mul_lo_u32, DI, REP8(X_MULLO), SI)
+#define X_MULHI(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+KERNEL(mul_hi_u32, DI, REP8(X_MULHI), SI)
+#define X_MAD24(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+KERNEL(mad_u32_u24, DI, REP8(X_MAD24), SI)
+#define DI64 unsigned long long a0 = (unsigned)seed, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; unsigned b = (unsigned)seed * 3 + 1, c = 7;
+#define SI64 if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345) out[0] = 1;
+#define X_MAD64(i) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(a##i) : "v"(b), "v"(c) : "s20", "s21");
+KERNEL(mad_u64_u32, DI64, REP8(X_MAD64), SI64)
+#define X_LSHLADD(i) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a##i) : "v"(b));
+KERNEL(lshl_add_u32, DI, REP8(X_LSHLADD), SI)
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 #define DPK f2 p0 = {(float)seed, 1.f}, p1 = p0 + 1.f, p2 = p0 + 2.f, p3 = p0 + 3.f, p4 = p0 + 4.f, p5 = p0 + 5.f, p6 = p0 + 6.f, p7 = p0 + 7.f, pb = p0 * 0.5f, pc = {1.0000001f, 0.9999999f};
@@ -159,7 +172,9 @@ int main()
                     {"v_cmp_lt_f32 vcc", k_cmp_f32_vcc}, {"v_cmp_lt_f32 sgpr", k_cmp_f32_sgpr}, {"v_cndmask_b32", k_cndmask_b32},
                     {"v_mov_b32", k_mov_b32}, {"v_or3_b32", k_or3_b32}, {"v_addc_co_u32", k_addc_u32}, {"v_readlane_b32", k_readlane}, {"v_fmac_f32 s,v", k_fmac_f32_sgpr}, {"v_fmac_f32 s2x,v", k_fmac_f32_sgpr_var}, {"v_mul_f32 s,v", k_mul_f32_sgpr}, {"v_fma_f32 s,v,-v", k_fma_f32_sgpr}, {"v_subrev_f32 s,v", k_subrev_f32_sgpr}, {"v_or_b32", k_or_b32}, {"sweep chain (11)", k_sweep_chain_x11}, {"v_alignbit_b32", k_alignbit}, {"v_sub_f32", k_sub_f32}, {"v_cndmask_b32 sgpr", k_cndmask_sgpr}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_mfma_f32_32x32x2", k_mfma_32x32x2_f32},
                     {"v_frexp_exp_i32_f64", k_frexp_exp_f64}, {"v_mov_b64", k_mov_b64}, {"v_min3_i32", k_min3_i32}, {"v_bfi_b32", k_bfi_b32},
-                    {"v_cmp_class_f64", k_cmp_class_f64}, {"v_add_u32", k_add_u32}, {"v_cmp_gt_u32", k_cmp_gt_u32}};
+                    {"v_cmp_class_f64", k_cmp_class_f64}, {"v_add_u32", k_add_u32}, {"v_cmp_gt_u32", k_cmp_gt_u32},
+                    {"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mad_u64_u32", k_mad_u64_u32},
+                    {"v_lshl_add_u32", k_lshl_add_u32}};
     unsigned long long *d;
     hipMalloc(&d, 1 << 20);
     printf("%-20s %10s %10s %10s %10s   (cycles per wave-instruction per SIMD = wave cycles / instrs * waves... see columns)\n", "instruction",
