@@ -179,7 +179,10 @@ TRT_DEV d3 reflect(d3 v, d3 n)
 // "integer indefinite" 0x80000000 for NaN / out-of-range (gfx950's v_cvt_i32_f64 saturates instead).
 TRT_DEV int d2i(double x)
 {
-    return (x > -2147483649.0 && x < 2147483648.0) ? (int)x : (int)0x80000000;
+    // |x| < 2^31: the truncation is exact.  Everything else -- NaN, x >= 2^31, x <= -2^31 -- is 0x80000000 on x86-64: the "integer
+    // indefinite", which for -2^31 - 1 < x <= -2^31 is also the truncated value.  One compare (the absolute value is a free
+    // operand modifier) instead of two.
+    return __builtin_fabs(x) < 2147483648.0 ? (int)x : (int)0x80000000;
 }
 
 // fmin(x, 1.0) of TRT.c:911/945 (NaN -> 1.0)
