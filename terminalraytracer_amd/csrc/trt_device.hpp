@@ -373,9 +373,9 @@ TRT_DEV uint32_t sky_texel(const uint32_t *sky, int dim, d3 direction)
 // later step (clamp, +0.5, *dim, truncation) can see it.  Assumes finite components.
 TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir, double dim_f)
 {
-    const double t[6] = {dir.x, -dir.x, dir.y, -dir.y, dir.z, -dir.z};
     int face = 0;
     double best = -1.0;
+    const double t[6] = {dir.x, -dir.x, dir.y, -dir.y, dir.z, -dir.z};
 #pragma unroll
     for (int f = 0; f < 6; f++)
         if (t[f] > best) // strict, first wins (TRT.c:708)

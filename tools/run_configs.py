@@ -17,12 +17,16 @@ def measure(name, scene, w, h, b, frames, cameras=None):
     d = hip.Dist(0, scene, None, 0, 1, w, h, tile_rows=8, frames_in_flight=3)
     ctx0 = d.context(0)
     fb = torch.zeros(h * w * 3, dtype=torch.float64, device="cuda:0")
+    cams = cameras or [scene.camera] * frames
     ctx0.enable_counters(True)
-    ctx0.render_device(scene.camera, hip.RowSet.whole(w, h), b, 10, fb.data_ptr(), fb.numel() * 8)
-    path, shadow = ctx0.read_counters()
+    counts = []
+    for c in (cameras or [scene.camera]):  # the same basis as bench.py: every camera of an orbit has its own ray count
+        ctx0.render_device(c, hip.RowSet.whole(w, h), b, 10, fb.data_ptr(), fb.numel() * 8)
+        counts.append(ctx0.read_counters())
+    path = sum(counts[i % len(counts)][0] for i in range(len(cams))) / len(cams)
+    shadow = sum(counts[i % len(counts)][1] for i in range(len(cams))) / len(cams)
     ctx0.enable_counters(False)
     del fb
-    cams = cameras or [scene.camera] * frames
     for c in cams[:3]:
         d.render(c, b, 10)
     d.synchronize()
