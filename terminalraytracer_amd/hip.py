@@ -500,6 +500,11 @@ class Dist:
         _dist_check(lib().trt_dist_fetch(self._h, _VP(device_frame), out.ctypes.data))
         return out
 
+    def set_scene(self, scene_data):
+        """another scene for every frame slot: the first slot builds its tables, the others share them (trt_dist_set_scene)"""
+        scene = scene_data.as_scene()
+        _dist_check(lib().trt_dist_set_scene(self._h, C.byref(scene)))
+
     def frame_times(self):
         """(render_ms, gather_ms) of this rank, averaged over the slots' most recent frames (trt_dist_frame_times)"""
         r, g = C.c_float(), C.c_float()

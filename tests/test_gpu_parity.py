@@ -1378,3 +1378,28 @@ def test_the_cube_instructions_equal_their_c_restatement(ctx):
     same = dev.view(np.uint32)[~null] == host.view(np.uint32)[~null]
     bad = (~same).any(axis=1)
     assert same.all(), (int(bad.sum()), v[~null][bad][:5], dev[~null][bad][:5], host[~null][bad][:5])
+
+
+def test_a_trt_dist_is_given_another_scene(ctx):
+    """trt_dist_set_scene: the first frame slot builds the new scene's tables, the other slots let go of the old ones and share the
+    new (one copy per device before and after); frames of both scenes, rendered through all three slots, are the oracle's."""
+    first = S.synth_scene(256, T.sky("synth"), T.bench_camera(96, 54))
+    second = S.synth_scene(40, T.sky("synth"), T.bench_camera(96, 54, 2.5), seed=3)
+    d = hip.Dist(0, first, None, 0, 1, 96, 54, tile_rows=8, frames_in_flight=3)
+    try:
+        for turn, scene in enumerate((first, second, first)):
+            if turn:
+                d.set_scene(scene)
+            info = [d.context(i).scene_info() for i in range(3)]
+            assert all(i["sharers"] == 3 and i["table_bytes"] == info[0]["table_bytes"] for i in info), info
+            want = {t: T.oracle_render(scene.with_camera(T.bench_camera(96, 54, t)), 96, 54, 6, 4)[0] for t in (1.0, 2.5, 10.0)}
+            frames = []
+            for t in (1.0, 2.5, 10.0, 1.0, 2.5):  # five frames through three slots: every slot, re-used
+                frames.append((t, d.render(T.bench_camera(96, 54, t), 6, 4)))
+                if len(frames) >= 3:
+                    t0, f0 = frames.pop(0)
+                    assert np.array_equal(bits(d.fetch(f0)), bits(want[t0])), (len(scene.spheres), t0)
+            for t0, f0 in frames[-1:]:
+                assert np.array_equal(bits(d.fetch(f0)), bits(want[t0]))
+    finally:
+        d.close()
