@@ -285,6 +285,13 @@ int trt_selftest_unit(trt_context *ctx, const double *xyzw, size_t n, double *fa
  * as the device computes them and as the host restatement does.  The two must agree bit for bit. */
 int trt_selftest_cube(trt_context *ctx, const float *xyz, size_t n, float *device_out, float *host_out);
 
+/* Tests: the skybox look-up of the production kernel (get_skybox_color, TRT.c:700-789) takes the texel's index from an FP32
+ * estimate of the texel coordinates whenever that provably truncates as the reference's FP64 value does, and from the FP64 form
+ * otherwise (csrc/trt_device.hpp: sky_index_estimate).  For n unit directions (3 doubles each) and a cubemap of side dim:
+ * exact[i] = face dim^2 + vi dim + ui by the FP64 form, estimate[i] = by the estimate, ambiguous[i] != 0 where the estimate
+ * does not vouch for itself.  The claim under test: ambiguous[i] == 0  =>  estimate[i] == exact[i]. */
+int trt_selftest_sky(trt_context *ctx, const double *dirs, size_t n, int dim, long long *exact, long long *estimate, int *ambiguous);
+
 /* Single-ray probe for tests: closest hit of TRT.c:793 for n rays (host arrays): obj[n],
  * point[3n], normal[3n], material[5n] (colour, reflectivity, specularity); lit[3n] = colour after
  * the lighting of TRT.c:894 for hits. */

@@ -1866,6 +1866,47 @@ __global__ void cube_selftest_kernel(const float *xyz, long n, float *out)
 }
 } // namespace
 
+namespace
+{
+// trt_selftest_sky: per direction the reference's texel index by the FP64 form, the FP32 estimate's, and whether the estimate
+// calls itself ambiguous (the kernel then takes the FP64 form)
+__global__ void sky_selftest_kernel(const double *dirs, long n, int dim, long *exact, long *estimate, int *ambiguous)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const trt::d3 d = trt::d3{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]};
+    bool amb;
+    exact[i] = trt::sky_index_unit(dim, d, (double)dim);
+    estimate[i] = trt::sky_index_estimate(dim, (float)dim, d, amb);
+    ambiguous[i] = amb;
+}
+} // namespace
+
+extern "C" int trt_selftest_sky(trt_context *ctx, const double *dirs, size_t n, int dim, long long *exact, long long *estimate, int *ambiguous)
+{
+    if (!ctx || !dirs || !exact || !estimate || !ambiguous || dim < 1)
+        return fail(TRT_ERR_ARGUMENT, "bad argument");
+    if (n == 0)
+        return TRT_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceBuffer<double> in;
+    DeviceBuffer<long> out;
+    DeviceBuffer<int> flags;
+    HIP_TRY(in.reserve(3 * n));
+    HIP_TRY(out.reserve(2 * n));
+    HIP_TRY(flags.reserve(n));
+    HIP_TRY(hipMemcpy(in.ptr, dirs, 3 * n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sky_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)in.ptr, (long)n, dim, out.ptr, out.ptr + n, flags.ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(exact, out.ptr, n * sizeof(long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(estimate, out.ptr + n, n * sizeof(long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ambiguous, flags.ptr, n * sizeof(int), hipMemcpyDeviceToHost));
+    in.release(), out.release(), flags.release();
+    return TRT_OK;
+}
+
 extern "C" int trt_selftest_cube(trt_context *ctx, const float *xyz, size_t n, float *device_out, float *host_out)
 {
     if (!ctx || !xyz || !device_out || !host_out)

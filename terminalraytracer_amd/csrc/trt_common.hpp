@@ -20,7 +20,20 @@ constexpr int kPersistentBlock = TRT_BLOCK;
 #ifndef TRT_STAMP
 #define TRT_STAMP 0
 #endif
-#if TRT_STAMP
+#if TRT_STAMP == 2
+// -DTRT_STAMP=2: the "clock" is s101, which tools/count_isa.py makes a count of executed instructions (it inserts an add at the
+// head of every basic block of the compiler's assembly: tools/build_isa_count.sh); the per-stage sums are then instruction counts
+#define TRT_STAMP_AT(slot)                                                  \
+    do                                                                      \
+    {                                                                       \
+        unsigned now_;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        asm volatile("s_mov_b32 %0, s101" : "=s"(now_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        stamp_sum[slot] += (unsigned)(now_ - (unsigned)stamp_prev);         \
+        stamp_prev = now_;                                                  \
+    } while (0)
+#elif TRT_STAMP
 #define TRT_STAMP_AT(slot)                                                                   \
     do                                                                                       \
     {                                                                                        \

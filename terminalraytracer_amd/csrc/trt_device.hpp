@@ -371,7 +371,7 @@ TRT_DEV uint32_t sky_texel(const uint32_t *sky, int dim, d3 direction)
 // resulting zeros is exact, so t_f = +-component, scale_by = the winning t, and u, v are +-0.5 * a
 // component of dir*(1/scale_by).  Only the sign of a zero can differ from the table form, and no
 // later step (clamp, +0.5, *dim, truncation) can see it.  Assumes finite components.
-TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir, double dim_f)
+TRT_DEV long sky_index_unit(int dim, d3 dir, double dim_f)
 {
     int face = 0;
     double best = -1.0;
@@ -417,12 +417,65 @@ TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir, double dim
     long idx = (long)ui + (long)vi * dim;
     const long last = (long)dim * dim - 1;
     idx = idx > last ? last : (idx < 0 ? 0 : idx);
-    return sky[(long)face * dim * dim + idx];
+    return (long)face * dim * dim + idx;
 }
+
+TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir, double dim_f) { return sky[sky_index_unit(dim, dir, dim_f)]; }
 
 TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir)
 {
     return sky_texel_unit(sky, dim, dir, (double)dim);
+}
+
+// The linear index (face dim^2 + vi dim + ui) of the same look-up from an FP32 ESTIMATE of the texel coordinates, with a proof
+// that it is the reference's index -- or `ambiguous`, and then the caller takes the FP64 path above.
+//   The reference forms U = (u + 0.5) dim, u = -+0.5 c / best (best = the largest |component|, c one of the other two; u and v
+// per face as derived in sky_texel_unit), and truncates.  Here the face and the two in-plane components come from the cube
+// instructions on the direction rounded to FP32 (v_cubeid / v_cubesc / v_cubetc / v_cubema: trt_cube_lookup in
+// csrc/trt_lightgrid.h restates them; in the reference's frames u = -sc / |ma|, v = tc / |ma| on every face but -Y, where both
+// signs flip), U' = fma(u', dim, dim / 2) in FP32.  Errors of U' against the real value: the roundings of the components
+// (2^-24 each, relative to |u| <= 1/2), the reciprocal (1 ulp, 2^-23), a product (2^-24) and the fma (2^-24 dim): below
+// 2^-21.9 dim; the reference's own U is within 2^-50 dim of the real value.  So with E = 2^-20 dim (3.7 x head-room) a U' that
+// lies in (E, dim - E) and whose fractional part lies in (E, 1 - E) truncates to the reference's ui; everything else -- a
+// coordinate next to a texel's edge, next to the face's edge (where the clamp of TRT.c:760 acts) or NaN (a direction that is
+// not finite or not of FP32's range) -- is ambiguous.  A WRONG FACE needs two components whose magnitudes agree to 2^-23: then
+// |c| / best is within 2^-22 of 1 and U' within E of 0 or dim: ambiguous.  dim >= 2^20 makes everything ambiguous.
+TRT_DEV long sky_index_estimate(int dim, float dim_f, d3 dir, bool &ambiguous)
+{
+    const float x = (float)dir.x, y = (float)dir.y, z = (float)dir.z;
+    const int face = (int)__builtin_amdgcn_cubeid(x, y, z);
+    const float sc = __builtin_amdgcn_cubesc(x, y, z), tc = __builtin_amdgcn_cubetc(x, y, z), ma = __builtin_amdgcn_cubema(x, y, z);
+    const float inv = __builtin_amdgcn_rcpf(__builtin_fabsf(ma)); // 1 / (2 best)
+    const unsigned flip = face == 3 ? 0x80000000u : 0u;
+    const float un = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sc) ^ flip ^ 0x80000000u) * inv; // u = -+sc / |ma|
+    const float vn = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tc) ^ flip) * inv;
+    const float half = 0.5f * dim_f, e = 0x1p-20f * dim_f;
+    const float U = __builtin_fmaf(un, dim_f, half), V = __builtin_fmaf(vn, dim_f, half);
+    const float fu = __builtin_amdgcn_fractf(U), fv = __builtin_amdgcn_fractf(V);
+    const float lo = __builtin_fminf(__builtin_fminf(U, V), __builtin_fminf(fu, fv)), hi = __builtin_fmaxf(U - dim_f + 1.0f, __builtin_fmaxf(V - dim_f + 1.0f, __builtin_fmaxf(fu, fv)));
+    ambiguous = !(lo > e && hi < 1.0f - e); // NaN: ambiguous
+    return ((long)face * dim + (long)(int)V) * dim + (long)(int)U;
+}
+
+#ifndef TRT_SKY_ESTIMATE
+#define TRT_SKY_ESTIMATE 1 // 0: always the FP64 form (A/B)
+#endif
+// the reference's index for the lanes with `active`: the estimate, and the FP64 form for a wave in which some lane's is ambiguous
+TRT_DEV long sky_index_unit(int dim, d3 dir, double dim_f);
+TRT_DEV uint32_t sky_texel_wave(const uint32_t *sky, int dim, d3 dir, double dim_f, bool active)
+{
+#if TRT_SKY_ESTIMATE
+    bool ambiguous;
+    long idx = sky_index_estimate(dim, (float)dim_f, dir, ambiguous);
+    if (__any(active && ambiguous))
+    {
+        const long exact = sky_index_unit(dim, dir, dim_f);
+        idx = ambiguous ? exact : idx;
+    }
+    return active ? sky[idx] : 0u;
+#else
+    return active ? sky[sky_index_unit(dim, dir, dim_f)] : 0u;
+#endif
 }
 
 TRT_DEV d3 texel_color(uint32_t t) // TRT.c:866: byte / 255.0

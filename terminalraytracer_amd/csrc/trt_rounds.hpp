@@ -287,7 +287,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
         const int per_shift = list_bits == 8 ? 3 : 2, per_mask = (1 << per_shift) - 1; // 8 or 4 entries per pool word
         unsigned long long cur = cell;
         int k = 0;
-#if TRT_STAMP
+#if TRT_STAMP == 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         TRT_TRACE_STAMP(0); // table load
@@ -971,7 +971,9 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
     bool waiting = false;                       // the sample ended on a hit whose colour arrives in the next round: the lane sits that round out
 
     TRT_STAGE_STAMPS(tally);
-#if TRT_STAMP
+#if TRT_STAMP == 2
+    stamp_prev = 0; // the instruction count starts at 0 at the kernel's entry (tools/count_isa.py); the prologue goes to the first slot
+#elif TRT_STAMP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     for (;;)
@@ -1067,8 +1069,8 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
             const double weight_before = weight;
             {
             TRT_FRESH_ARGS;
-            if (path_sky)
-                sky_t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f); // TRT.c:858-867; added to the sample after the colours still on their way
+            if (__any(path_sky))
+                sky_t = sky_texel_wave(s.sky, s.sky_dim, hit.back, s.sky_dim_f, path_sky); // TRT.c:858-867; added to the sample after the colours still on their way
             // ---- a hit becomes a task; what does not depend on its colour happens now (TRT.c:1036-1038, :1054) ----
             const unsigned long long hits = __ballot(path_hit);
             if (hits)
@@ -1183,13 +1185,13 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         bool end_sample = false;
         double weight_sum_new = weight_sum + weight; // TRT.c:1034
         uint32_t sky_t = 0;
-        if (path_sky)
+        if (__any(path_sky))
         { // TRT.c:858-867, :1044-1048: colour = texel, the sample ends here.  The texel is only LOADED here: it is a dependent read
           // from global memory, and what uses it (the sample's colour) is not needed before the END of the round, behind the other
           // lanes' shadow stages
             TRT_FRESH_ARGS;
-            sky_t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f);
-            end_sample = true;
+            sky_t = sky_texel_wave(s.sky, s.sky_dim, hit.back, s.sky_dim_f, path_sky);
+            end_sample = path_sky;
         }
         d3 lit;
         if (!REFRACT)
@@ -1339,6 +1341,7 @@ __global__ __launch_bounds__(kPersistentBlock) void probe_rounds_kernel(SceneVie
     const PathHit hit = path_stage<false, false, PATCHES>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally);
     const d3 surface = hit.hit ? add(hit.ph.p, scale(hit.back, 0.000001)) : o; // TRT.c:873-874 / :860
     const d3 lit = shadow_stage<false>(L, cull, grids, n, nd, nl, surface, hit.normal, hit.mat, hit.hit, gp, gn, tally);
+    const uint32_t sky_t = sky_texel_wave(s.sky, s.sky_dim, hit.back, s.sky_dim_f, alive && !hit.hit); // the render kernels' look-up
     if (!alive)
         return;
     d3 color = d3{0.0, 0.0, 0.0};
@@ -1353,7 +1356,7 @@ __global__ __launch_bounds__(kPersistentBlock) void probe_rounds_kernel(SceneVie
     }
     else
     {
-        const uint32_t t = sky_texel_unit(s.sky, s.sky_dim, hit.back, s.sky_dim_f);
+        const uint32_t t = sky_t;
         color = d3{L.b255[t & 0xFF], L.b255[(t >> 8) & 0xFF], L.b255[(t >> 16) & 0xFF]};
     }
     obj[i] = hit.hit ? (hit.ph.i < n ? 1 : 2) : 0;

@@ -93,6 +93,7 @@ SYMBOLS = {
     "trt_get_stream": (_I, [_VP, C.POINTER(C.c_void_p)]),
     "trt_selftest_cube": (_I, [_VP, _VP, C.c_size_t, _VP, _VP]),
     "trt_selftest_unit": (_I, [_VP, _VP, C.c_size_t, _VP, _VP]),
+    "trt_selftest_sky": (_I, [_VP, _VP, C.c_size_t, _I, _VP, _VP, _VP]),
     "trt_read_light_grid": (C.c_long, [_VP, _I, _I, _VP, C.c_size_t]),
     "trt_kernel_info": (_I, [_VP] + [C.POINTER(_I)] * 5),
     "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
@@ -307,6 +308,15 @@ class Context:
         dev, host = np.zeros((v.shape[0], 4), dtype=np.float32), np.zeros((v.shape[0], 4), dtype=np.float32)
         _check(lib().trt_selftest_cube(self._h, v.ctypes.data, v.shape[0], dev.ctypes.data, host.ctypes.data))
         return dev, host
+
+    def selftest_sky(self, dirs, dim):
+        """(exact, estimate, ambiguous): texel index of unit directions by the FP64 form of the skybox look-up, by the FP32 estimate,
+        and where the estimate does not vouch for itself (trt_selftest_sky)"""
+        v = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        exact, est = np.zeros(v.shape[0], dtype=np.int64), np.zeros(v.shape[0], dtype=np.int64)
+        amb = np.zeros(v.shape[0], dtype=np.int32)
+        _check(lib().trt_selftest_sky(self._h, v.ctypes.data, v.shape[0], int(dim), exact.ctypes.data, est.ctypes.data, amb.ctypes.data))
+        return exact, est, amb
 
     def read_light_grid(self, point_light, index, words):
         """one light's device-built candidate table as uint64 words (trt_read_light_grid)"""

@@ -1403,3 +1403,42 @@ def test_a_trt_dist_is_given_another_scene(ctx):
                 assert np.array_equal(bits(d.fetch(f0)), bits(want[t0]))
     finally:
         d.close()
+
+
+@pytest.mark.gpu
+def test_the_sky_estimate_vouches_only_for_the_reference_index(ctx):
+    """get_skybox_color (TRT.c:700-789): the kernel takes the texel's index from an FP32 estimate where that provably truncates as
+    the reference's FP64 value does (csrc/trt_device.hpp: sky_index_estimate).  Wherever the estimate is not ambiguous it must
+    equal the FP64 form: random directions, directions ON texel edges, on face edges and corners, axis directions, and cubemaps
+    from 1 to 2^21 texels a side (from 2^20 on everything must be ambiguous)."""
+    rng = np.random.default_rng(77)
+    for dim in (1, 2, 3, 64, 256, 1000, 2048, 8192, 1 << 20, 1 << 21):
+        v = rng.normal(size=(400_000, 3))
+        # points of the cube's surface that sit exactly on texel edges (and a few ulps off them), on every face
+        face = rng.integers(0, 6, size=200_000)
+        a = (rng.integers(0, dim + 1, size=200_000) / dim) * 2.0 - 1.0
+        b = rng.uniform(-1, 1, size=200_000)
+        a = a * (1.0 + rng.choice([0.0, 0.0, 1e-16, -1e-16, 1e-9, -1e-9, 1e-7, -1e-7, 3e-6, -3e-6], size=200_000))
+        swap = rng.integers(0, 2, size=200_000).astype(bool)
+        pa, pb = np.where(swap, b, a), np.where(swap, a, b)
+        major = np.where(face & 1, -1.0, 1.0)
+        cube = np.zeros((200_000, 3))
+        ax = face >> 1
+        for k in range(3):
+            m = ax == k
+            cube[m, k] = major[m]
+            cube[m, (k + 1) % 3] = pa[m]
+            cube[m, (k + 2) % 3] = pb[m]
+        # edges and corners of the cube: two or three components of equal magnitude
+        edge = rng.choice([-1.0, 1.0], size=(50_000, 3)) * np.where(rng.random((50_000, 3)) < 0.6, 1.0, rng.random((50_000, 3)))
+        axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 1], [-1, -1, -1], [1, -1, 0], [0, 1, -1]], dtype=np.float64)
+        dirs = np.concatenate([v, cube, edge, axes])
+        dirs = dirs / np.linalg.norm(dirs, axis=1, keepdims=True)
+        exact, est, amb = ctx.selftest_sky(dirs, dim)
+        sure = amb == 0
+        assert np.array_equal(exact[sure], est[sure]), (dim, int((exact[sure] != est[sure]).sum()))
+        assert exact.min() >= 0 and exact.max() < 6 * dim * dim
+        if dim >= 1 << 20:
+            assert not sure.any()
+        elif dim <= 2048:
+            assert sure[: len(v)].mean() > 0.98, (dim, sure[: len(v)].mean())  # the estimate is what usually runs
