@@ -375,14 +375,35 @@ __global__ void build_pointgrid_kernel(const trt_pointgrid_cone *cones, int n, i
 // The counter has 64 bits: it keeps counting after the pool is exhausted (exhaustion is a normal mode: the cell then says "no
 // list" and its rays sweep), and a 32-bit one would wrap after 2^32 words' worth of requests and hand out words that earlier
 // cells already point to.
+// Called by EVERY lane of a wave (`valid`: the lane has a cell): the lanes' requests are summed and the wave takes its words
+// with ONE atomic -- a request per cell on the one counter serialises in L2 (the eye's tables at 256 spheres: 49 152 cells
+// with pooled lists, ~0.1 ms of nothing but that).
 __device__ unsigned long long pack_cell(const unsigned long long *mask, int words, unsigned long long *pool, unsigned long long *pool_used,
-                                        unsigned pool_limit, int bits)
+                                        unsigned pool_limit, int bits, bool valid = true)
 {
-    const int count = trt_list_count(mask, words);
-    const unsigned need = trt_list_pool_words(count, bits);
+    const int count = valid ? trt_list_count(mask, words) : 0;
+    const unsigned need = valid ? trt_list_pool_words(count, bits) : 0u;
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned upto = need; // inclusive prefix sum over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        const unsigned below = __shfl_up(upto, d);
+        upto += lane >= d ? below : 0u;
+    }
+    const unsigned total = __shfl(upto, 63);
+    unsigned long long base = 0;
+    if (total)
+    {
+        if (lane == 63)
+            base = atomicAdd(pool_used, (unsigned long long)total);
+        base = __shfl(base, 63);
+    }
+    if (!valid)
+        return 0ull;
     if (need == 0)
         return trt_list_pack(mask, words, count, nullptr, 0u, bits);
-    const unsigned long long at = atomicAdd(pool_used, (unsigned long long)need);
+    const unsigned long long at = base + (upto - need);
     if (count > 0xffff || at + need > (unsigned long long)pool_limit)
         return (unsigned long long)TRT_LIST_NONE << 56;
     return trt_list_pack(mask, words, count, pool, (unsigned)at, bits);
@@ -394,33 +415,97 @@ __global__ void pack_lists_kernel(const unsigned long long *masks, long cells, i
                                   unsigned long long *pool_used, unsigned pool_limit, int bits)
 {
     const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell < cells)
-        lists[cell] = pack_cell(masks + cell * words, words, pool, pool_used, pool_limit, bits);
+    const bool valid = cell < cells;
+    const unsigned long long packed = pack_cell(masks + (valid ? cell : 0) * words, words, pool, pool_used, pool_limit, bits, valid);
+    if (valid)
+        lists[cell] = packed;
 }
 
-// Direction tables of path-ray families (trt_raygrid.h): blockIdx.y = family, one thread per cell.  Every block first forms
-// the cones of its family's apex (the same + - * / sqrt as the host reference builder: the same bits), then each thread
-// marks its cell with the cone / cell predicate of trt_lightgrid.h and packs the list.  `by_value`: the two families of the
-// eye come as kernel arguments (they change with the camera), otherwise family blockIdx.y of `families`.
+// Direction tables of path-ray families (trt_raygrid.h): blockIdx.y = family.  When the table's side is a multiple of 8 a
+// workgroup builds one TILE of 8 x 8 cells: every block first forms the cones of its family's apex (the same + - * / sqrt as
+// the host reference builder: the same bits), thread i asks whether sphere i's cone reaches the TILE at all (trt_raygrid.h
+// "marking the cells": the table's bit is tile AND cell), and then the four waves share the spheres that do -- wave q takes
+// every fourth one -- each lane marking ITS cell with the cone / cell predicate of trt_lightgrid.h; the waves' masks are
+// OR-ed in LDS and the first wave packs the lists.  (Every cell asking every sphere, 256 cells per block, took 0.95 ms per
+// camera for the eye's two tables at 256 spheres: 192 blocks of long dependent FP64 chains.  Tiles of 16 x 16: 0.16 ms.)
+// Otherwise: one thread per cell, 256 consecutive cells per block, every sphere.  `by_value`: the two families of the eye come
+// as kernel arguments (they change with the camera), otherwise family blockIdx.y of `families`.
+static_assert(TRT_FAMILY_TILE * TRT_FAMILY_TILE == 64 && TRT_LIST_MAX_SPHERES <= 256, "a tile per wave, a sphere per thread");
+constexpr int kSceneTilesPerBlock = 16; // the scene's sphere families: thousands of tables, 16 tiles from one set of cones
+unsigned family_grid_blocks(int g, int tiles_per_block)
+{
+    const unsigned cells = 6u * (unsigned)g * (unsigned)g;
+    return trt_family_tiled(g) ? (cells / 64u + (unsigned)tiles_per_block - 1u) / (unsigned)tiles_per_block : (cells + 255u) / 256u;
+}
+
 __global__ __launch_bounds__(256) void build_family_lists_kernel(const double *spheres, int n, const trt_rayfamily *families, trt_rayfamily f0,
                                                                  trt_rayfamily f1, int by_value, int g, unsigned long long *lists,
-                                                                 unsigned long long *pool, unsigned long long *pool_used, unsigned pool_limit)
+                                                                 unsigned long long *pool, unsigned long long *pool_used, unsigned pool_limit,
+                                                                 int tiles_per_block)
 {
+    constexpr int kWords = TRT_LIST_MAX_SPHERES / 64;
     __shared__ trt_pointgrid_cone cones[TRT_LIST_MAX_SPHERES];
+    __shared__ unsigned long long reach[kWords];          // bit k of word w: sphere 64 w + k reaches this block's tile
+    __shared__ unsigned long long part[4][64][kWords];    // wave q's marks of the tile's cells
     const trt_rayfamily F = by_value ? (blockIdx.y == 0 ? f0 : f1) : families[blockIdx.y];
     for (int i = threadIdx.x; i < n; i += blockDim.x)
         trt_rayfamily_cone(&F, spheres + 9 * i, &cones[i]);
     __syncthreads();
     const unsigned cells = 6u * (unsigned)g * (unsigned)g;
-    const unsigned cell = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= cells)
+    const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
+    if (!trt_family_tiled(g))
+    {
+        const unsigned cell = blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = cell < cells;
+        const int face = (int)(cell / ((unsigned)g * (unsigned)g)), j = (int)((cell / (unsigned)g) % (unsigned)g), c = (int)(cell % (unsigned)g);
+        unsigned long long m[kWords] = {0, 0, 0, 0};
+        for (int i = 0; valid && i < n; i++)
+            if (trt_pointgrid_reaches(&cones[i], face, c, j, g))
+                m[i >> 6] |= 0x8000000000000000ull >> (i & 63);
+        const unsigned long long packed = pack_cell(m, words, pool, pool_used, pool_limit, 8, valid);
+        if (valid)
+            lists[(size_t)blockIdx.y * cells + cell] = packed;
         return;
-    const int face = (int)(cell / ((unsigned)g * (unsigned)g)), j = (int)((cell / (unsigned)g) % (unsigned)g), c = (int)(cell % (unsigned)g);
-    unsigned long long m[TRT_LIST_MAX_SPHERES / 64] = {0, 0, 0, 0};
-    for (int i = 0; i < n; i++)
-        if (trt_pointgrid_reaches(&cones[i], face, c, j, g))
-            m[i >> 6] |= 0x8000000000000000ull >> (i & 63);
-    lists[(size_t)blockIdx.y * cells + cell] = pack_cell(m, (n + 63) / 64 > 0 ? (n + 63) / 64 : 1, pool, pool_used, pool_limit, 8);
+    }
+    // block -> tiles_per_block consecutive tiles (the scene's tables: thousands of families, a block builds a face's worth of
+    // tiles from ONE set of cones; the eye's two tables: a tile per block, for the parallelism)
+    const unsigned gt = (unsigned)g / TRT_FAMILY_TILE, tiles = 6u * gt * gt;
+    const int lane = (int)(threadIdx.x & 63), q = (int)(threadIdx.x >> 6);
+    for (unsigned tile = blockIdx.x * (unsigned)tiles_per_block; tile < tiles && tile < (blockIdx.x + 1u) * (unsigned)tiles_per_block; tile++)
+    {
+        const int face = (int)(tile / (gt * gt)), tj = (int)((tile / gt) % gt), tc = (int)(tile % gt);
+        const bool reaches = (int)threadIdx.x < n && trt_pointgrid_reaches(&cones[threadIdx.x], face, tc, tj, (int)gt);
+        const unsigned long long word = __ballot(reaches); // the 64 spheres of this wave
+        __syncthreads(); // the previous tile's reach[] and part[] have been read
+        if (lane == 0)
+            reach[q] = word;
+        __syncthreads();
+        const int j = tj * TRT_FAMILY_TILE + lane / TRT_FAMILY_TILE, c = tc * TRT_FAMILY_TILE + lane % TRT_FAMILY_TILE;
+#pragma unroll
+        for (int w = 0; w < kWords; w++)
+        {
+            unsigned long long m = 0;
+            unsigned long long todo = 64 * w < n ? reach[w] & (0x1111111111111111ull << q) : 0ull; // the same in every lane of the wave: a scalar loop
+            while (todo)
+            {
+                const int k = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                if (trt_pointgrid_reaches(&cones[64 * w + k], face, c, j, g))
+                    m |= 0x8000000000000000ull >> k;
+            }
+            part[q][lane][w] = m;
+        }
+        __syncthreads();
+        if (q == 0)
+        {
+            unsigned long long m[kWords];
+#pragma unroll
+            for (int w = 0; w < kWords; w++)
+                m[w] = part[0][lane][w] | part[1][lane][w] | part[2][lane][w] | part[3][lane][w];
+            const unsigned cell = ((unsigned)face * (unsigned)g + (unsigned)j) * (unsigned)g + (unsigned)c;
+            lists[(size_t)blockIdx.y * cells + cell] = pack_cell(m, words, pool, pool_used, pool_limit, 8);
+        }
+    }
 }
 
 // Light-space candidate masks of every light (trt_lightgrid.h), from the context's host copy of the primitives: the
@@ -563,9 +648,10 @@ int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const double *
         for (size_t first = 0; first < families; first += 32768) // grid.y is limited to 65535
         {
             const unsigned batch = (unsigned)std::min<size_t>(32768, families - first);
-            hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((sph_cells + 255) / 256), batch), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(build_family_lists_kernel, dim3(family_grid_blocks(gs, kSceneTilesPerBlock), batch), dim3(256), 0, ctx->stream,
                                (const double *)ctx->T->d_spheres.ptr, n, (const trt_rayfamily *)ctx->T->d_families.ptr + first, trt_rayfamily{}, trt_rayfamily{}, 0,
-                               gs, ctx->T->d_path_lists.ptr + eye_part + first * sph_cells, ctx->T->d_pool.ptr, ctx->T->d_pool_used.ptr, (unsigned)ctx->T->pool_scene_words);
+                               gs, ctx->T->d_path_lists.ptr + eye_part + first * sph_cells, ctx->T->d_pool.ptr, ctx->T->d_pool_used.ptr, (unsigned)ctx->T->pool_scene_words,
+                               kSceneTilesPerBlock);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -634,9 +720,9 @@ int ensure_eye_tables(trt_context *ctx, const Camera *camera, hipStream_t stream
     const size_t pool_from = ctx->T->pool_scene_words + (size_t)ctx->eye_slot * ctx->T->pool_eye_words;
     unsigned long long *const counter = ctx->T->d_pool_used.ptr + 16 * (1 + ctx->eye_slot);
     hipLaunchKernelGGL(set_pool_counter_kernel, dim3(1), dim3(1), 0, stream, counter, (unsigned long long)pool_from);
-    hipLaunchKernelGGL(build_family_lists_kernel, dim3((unsigned)((eye_cells + 255) / 256), 2u), dim3(256), 0, stream, (const double *)ctx->T->d_spheres.ptr, n,
+    hipLaunchKernelGGL(build_family_lists_kernel, dim3(family_grid_blocks(ge, 1), 2u), dim3(256), 0, stream, (const double *)ctx->T->d_spheres.ptr, n,
                        (const trt_rayfamily *)nullptr, g.eye[0], g.eye[1], 1, ge, ctx->T->d_path_lists.ptr + g.eye_at, ctx->T->d_pool.ptr, counter,
-                       (unsigned)(pool_from + ctx->T->pool_eye_words));
+                       (unsigned)(pool_from + ctx->T->pool_eye_words), 1);
     HIP_TRY(hipGetLastError());
     memcpy(ctx->eye_built, eye, sizeof eye);
     ctx->eye_tables_valid = true;
