@@ -4,7 +4,9 @@ compared bit for bit with the oracle.  usage: python tools/fuzz_campaign.py [fir
 modes: "" generic | wide | lights | compact (decoupled shading forced on) | refract (extension, against its own restatement) |
 dense: 128..256 spheres packed tightly, the library's default patches (or 6 / 54 / 96) |
 patches / patches_refract: a family per PATCH of a sphere's surface (trt_set_path_patches 1..4, random table resolutions, the
-three scene generators in turn), tables for every scene."""
+three scene generators in turn), tables for every scene. |
+sky: few small spheres, cubemaps of any side (1 ... 1031 texels, powers of two and not, procedural: every texel its own colour), the
+camera turned anywhere and placed anywhere (the skybox look-up's FP32 estimate and its FP64 fall-back, csrc/trt_device.hpp)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -79,9 +81,31 @@ def dense_scene(rng, w, h):
     return S.SceneData(sph, ground, d, p, cam, T.sky("synth"))
 
 
+def sky_scene(rng, w, h):
+    """Most rays end on the sky: 0..4 small spheres, a ground that may face away, a cubemap of a random side whose texels all
+    differ, a camera with a random orthonormal basis somewhere near or far from the origin."""
+    n = int(rng.integers(0, 5))
+    sph = np.zeros((n, 9))
+    sph[:, :3] = rng.normal(size=(n, 3)) * 3.0
+    sph[:, 3] = rng.uniform(0.05, 0.6, n)
+    sph[:, 4:7] = rng.uniform(0, 1, (n, 3))
+    sph[:, 7] = rng.choice([0.0, 0.9, 1.0], n)
+    sph[:, 8] = 100.0
+    ground = S.demo_ground().copy()
+    ground[0:3] = [0.0, -float(rng.choice([1.0, 50.0, 1e4])), 0.0]
+    ground[9] = rng.choice([0.0, 1.0])
+    d, p = S.demo_lights()
+    cam = T.bench_camera(w, h, float(rng.choice([0.0, 0.5, 2.5, 10.0])))
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))  # a random rotation of the camera's basis: every face of the cubemap gets looked at
+    cam[0:9] = (cam[0:9].reshape(3, 3) @ q.T).reshape(9)
+    cam[9:12] = rng.normal(size=3) * 10.0 ** rng.uniform(-2, 2)
+    dim = int(rng.choice([1, 2, 3, 5, 8, 31, 64, 100, 255, 256, 257, 513, 1031]))
+    return S.SceneData(sph, ground, d, p, cam, S.synth_sky(dim))
+
+
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
-make = {"wide": wide_scene, "lights": light_heavy_scene, "compact": light_heavy_scene, "dense": dense_scene}.get(mode, P._fuzz_scene)
+make = {"wide": wide_scene, "lights": light_heavy_scene, "compact": light_heavy_scene, "dense": dense_scene, "sky": sky_scene}.get(mode, P._fuzz_scene)
 patches = mode.startswith("patches")
 refract = mode in ("refract", "patches_refract")  # EXTENSION, parity unpinned: against the oracle's restatement of the extension, not the reference
 bad = 0
