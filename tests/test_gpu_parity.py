@@ -117,6 +117,11 @@ def test_production_stages_match_reference_single_ray_vectors(ctx, grids):
             garbage[2::4] = 2 ** 31 - 1
             garbage[3::4] = -7
             _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], garbage.astype(np.int32)), want)
+            # one to four rays of a wave without a family (every 17th ray; every 64th ray and its three neighbours): their waves sweep
+            for lone in (np.arange(len(codes)) % 17 == 5, np.arange(len(codes)) % 64 < 4, np.arange(len(codes)) % 64 == 63):
+                few = np.array(codes, dtype=np.int32)
+                few[lone] = -1
+                _same_probe(ctx.probe_rays_production(scene.camera, fam[tag + "/rays"], few), want)
             _same_probe(ctx.probe_rays(fam[tag + "/rays"]), want)  # and the reference-order kernel's probe
     finally:
         ctx.set_path_patches(-1)
@@ -1442,3 +1447,35 @@ def test_the_sky_estimate_vouches_only_for_the_reference_index(ctx):
             assert not sure.any()
         elif dim <= 2048:
             assert sure[: len(v)].mean() > 0.98, (dim, sure[: len(v)].mean())  # the estimate is what usually runs
+
+
+@pytest.mark.gpu
+def test_rays_beyond_the_tables_range(ctx):
+    """A camera high above a small scene sees ground out to the horizon: the shadow rays and the reflections that start there lie
+    beyond the tables' range (256 x the scene's reach) and their waves sweep the culling table instead -- a few of them per wave
+    in the view towards the horizon, all of them in the view from 1e7 up.  The frames are the oracle's either way, and the sweeps
+    must have happened."""
+    for n, spp in ((6, 3), (64, 1)):
+        base = (S.synth_scene(n, T.sky("synth"), T.bench_camera(192, 108)) if n > 6 else
+                T.golden_scene(next(c for c in T.golden_cases() if c["name"] == "demo_160x48_b4")))
+        ground = np.array(base.ground, dtype=np.float64).copy()
+        ground[9] = 0.6  # a reflecting ground: path rays start out there too
+        for height, tilt in ((40.0, -0.06), (1e7, -0.7)):
+            cam = np.array(base.camera, dtype=np.float64).copy()
+            cam[9:12] = [0.0, height, 0.0]
+            fwd = np.array([0.0, tilt, -1.0]) / np.linalg.norm([0.0, tilt, -1.0])
+            right = np.cross(fwd, [0.0, 1.0, 0.0]); right /= np.linalg.norm(right)
+            up = np.cross(right, fwd)
+            cam[0:3], cam[3:6], cam[6:9] = right, up, -fwd
+            scene = S.SceneData(base.spheres, ground, base.dir_lights, base.point_lights, cam, base.sky)
+            ctx.set_scene(scene)
+            ctx.enable_counters(True)
+            try:
+                got = render(ctx, scene, 192, 108, 4, spp, hip.Context.PRODUCTION)
+                ctx.read_counters()
+                diag = ctx.read_diagnostics()
+            finally:
+                ctx.enable_counters(False)
+            want = T.oracle_render(scene, 192, 108, 4, spp)[0]
+            assert np.array_equal(bits(got), bits(want)), (n, height)
+            assert diag["swept_traces"] > 0 or height < 1e6, (n, height, diag)
