@@ -425,6 +425,7 @@ TRT_HD int trt_list_entry(unsigned long long cell, const unsigned long long *poo
  * (csrc/trt_capi.hip: build_family_lists_kernel, a tile per workgroup; the eye's tables, which are rebuilt whenever the
  * camera moves, took 0.95 ms at 256 spheres with every cell asking every sphere). */
 #define TRT_FAMILY_TILE 8
+#define TRT_LIST_MAX_SPHERES_HOST 256 /* the host builder caches a tile row's answers for up to this many spheres */
 TRT_HD int trt_family_tiled(int g) { return g >= TRT_FAMILY_TILE && g % TRT_FAMILY_TILE == 0; }
 
 /* ---- host reference builder (tests; the library marks the cells on the device with the same predicates) ---- */
@@ -436,19 +437,32 @@ static inline long trt_rayfamily_build(const double *spheres, int n, const trt_r
         trt_rayfamily_cone(F, spheres + 9 * i, cones + i);
     const int tiled = trt_family_tiled(g), gt = g / TRT_FAMILY_TILE;
     long bits = 0;
+    long tile_of_row = -1;                 /* the tile row whose answers `reach` holds: (face, j / TILE) */
+    unsigned char reach[64 * TRT_LIST_MAX_SPHERES_HOST]; /* [tile column][sphere]: does the cone reach the tile?  (gt <= 64 columns) */
     for (long cell = 0; cell < 6L * g * g; cell++)
     {
         unsigned long long *m = masks + cell * words;
         for (int w = 0; w < words; w++)
             m[w] = 0;
         const int face = (int)(cell / ((long)g * g)), j = (int)((cell / g) % g), c = (int)(cell % g);
+        const int cached = tiled && gt <= 64 && n <= TRT_LIST_MAX_SPHERES_HOST;
+        if (cached && tile_of_row != (long)face * gt + j / TRT_FAMILY_TILE)
+        {
+            tile_of_row = (long)face * gt + j / TRT_FAMILY_TILE;
+            for (int tc = 0; tc < gt; tc++)
+                for (int i = 0; i < n; i++)
+                    reach[tc * TRT_LIST_MAX_SPHERES_HOST + i] = (unsigned char)trt_pointgrid_reaches(cones + i, face, tc, j / TRT_FAMILY_TILE, gt);
+        }
         for (int i = 0; i < n; i++)
-            if ((!tiled || trt_pointgrid_reaches(cones + i, face, c / TRT_FAMILY_TILE, j / TRT_FAMILY_TILE, gt)) &&
-                trt_pointgrid_reaches(cones + i, face, c, j, g))
+        {
+            const int in_tile = !tiled ? 1 : (cached ? reach[(c / TRT_FAMILY_TILE) * TRT_LIST_MAX_SPHERES_HOST + i]
+                                                    : trt_pointgrid_reaches(cones + i, face, c / TRT_FAMILY_TILE, j / TRT_FAMILY_TILE, gt));
+            if (in_tile && trt_pointgrid_reaches(cones + i, face, c, j, g))
             {
                 trt_lightgrid_set(m, i);
                 bits++;
             }
+        }
     }
     return bits;
 }
