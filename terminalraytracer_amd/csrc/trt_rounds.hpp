@@ -174,6 +174,19 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
             l_patch[i] = grids.patch_rec[i];
     }
     __syncthreads();
+    // A directional light's table is for rays along its UNIT direction (trt_lightgrid.h): a light whose direction could not be
+    // normalised (TRT.c:444 leaves vectors shorter than 1e-4 alone) gets a range no origin is in -- "far" for every ray, its waves
+    // sweep -- here, once per workgroup, instead of the shading stage testing |sd.sd - 1| for every light in every pass.
+    if (grids.enabled)
+    {
+        for (int i = threadIdx.x; i < nd; i += blockDim.x)
+        {
+            const d3 sd = load3(l_dir + i * 6);
+            if (!(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13))
+                ((trt_dirgrid *)l_dirgrid)[i].rg2 = -1.0f;
+        }
+        __syncthreads();
+    }
     return LdsImage{l_cull, l_cull_dir, l_sph, l_mat, l_dir, l_pt, l_255, l_cam, l_jit,
                     (const trt_dirgrid *)l_dirgrid, (const trt_pointgrid *)l_pointgrid, l_fam, l_eye, l_patch};
 }
@@ -717,8 +730,7 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
             {
                 const trt_dirgrid *G = L.dirgrid + li; // header in LDS: a global read here would sit in front of the cell's load
                 int far;
-                const int c = trt_dirgrid_cell(G, o.x, o.y, o.z, &far);
-                far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
+                const int c = trt_dirgrid_cell(G, o.x, o.y, o.z, &far); // a light without a unit direction: far (stage_lds_image)
                 if (lit_lanes && !far)
                     cell = grids.dir_lists[(size_t)li * grids.dir_stride + (unsigned)c];
                 use_list = !__any(lit_lanes && (far || (unsigned)(cell >> 56) == TRT_LIST_NONE));
