@@ -278,7 +278,10 @@ static bool renders_decoupled(const trt_context *ctx, long units)
         return false;
     if (ctx->grids.path_enabled && ctx->grids.patch_m) // scenes whose spheres have patches (dense ones) run the plain rounds
         return false;
-    const bool pays = ctx->scene.num_dir + ctx->scene.num_point >= kCompactionMinLights && units >= kCompactionMinUnits &&
+    // ... and only scenes whose path rays are served by tables: with the few spheres of a scene that sweeps (BASELINE configs[1]:
+    // 8 spheres, most rays end on the ground or the sky) the ring costs more than the idle lanes (round 4, final kernel,
+    // profiles/r04/i_all_configs_one_gpu.md: 43.3 G path rays/s plain against 40.8 decoupled; config 3 equal, config 4 +4 % decoupled)
+    const bool pays = ctx->scene.num_dir + ctx->scene.num_point >= kCompactionMinLights && units >= kCompactionMinUnits && ctx->grids.path_enabled &&
                       ctx->compact_blocks_per_cu * trt::kCompactBlock >= ctx->rounds_blocks_per_cu * trt::kPersistentBlock;
     return ctx->compaction > 0 || pays;
 }

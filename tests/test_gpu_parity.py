@@ -189,8 +189,9 @@ def test_baseline_configs_whole_frames_equal_reference_hash_and_oracle(ctx, name
     produced for it (tests/golden/golden_full.json), the (int)(c*255) bytes likewise, the reference-order kernel -- an
     independent HIP implementation -- agrees, and so do the trace_ray call counts.  The counting instantiation of the kernel is
     another binary than the one that ships (other register allocation): the frame is rendered once more WITHOUT counters -- the
-    instantiation bench.py times: <false, false, true> (shading decoupled) for c2 / c3 / c4,
-    <false, false, false, true> (a family per patch of a sphere) for c5 -- and must have the same bits."""
+    instantiation bench.py times: <false, false, true> (shading decoupled) for c3 / c4, the plain rounds for c2 (8 spheres: its
+    path rays sweep, and a scene that sweeps is not decoupled), <false, false, false, true> (a family per patch of a sphere) for
+    c5 -- and must have the same bits."""
     import os
     case = T.golden_full()[name]
     w, h, b, spp = case["width"], case["height"], case["bounce_limit"], case["rays_per_pixel"]
@@ -218,7 +219,7 @@ def test_baseline_configs_whole_frames_equal_reference_hash_and_oracle(ctx, name
         del fb
         variant = ctx.render_variant()
         n = len(scene.spheres)
-        assert variant["decoupled"] == (n < 128) and ctx.path_patches() == ((2, 24) if n == 256 else ((0, 1) if n >= 12 else (0, 0))), (variant, n)
+        assert variant["decoupled"] == (12 <= n < 128) and ctx.path_patches() == ((2, 24) if n == 256 else ((0, 1) if n >= 12 else (0, 0))), (variant, n)
     finally:
         ctx.set_path_grids_min_spheres(0)
     assert np.array_equal(bits(shipped), bits(fast)) and T.fnv(shipped) == case["fb_fnv"]
