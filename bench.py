@@ -178,7 +178,7 @@ def other_configs(hip, host, torch, local, depth, tile_rows):
     of them.  Ray counts: the reference's own (golden_full.json) for the stills, the kernel's counting variant (untimed) for the
     60 cameras of the orbit."""
     out = {}
-    for name, steps, frames in (("c2", 12, 0), ("c4", 6, 0), ("c5", 60, 60)):
+    for name, steps, frames in (("c2", 30, 0), ("c4", 12, 0), ("c5", 60, 60)):
         wl = WORKLOADS[name]
         w, h, b = wl["width"], wl["height"], wl["bounces"]
         scene = build_scene(name)
