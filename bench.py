@@ -295,7 +295,7 @@ def committed_profile():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed frames (default 20; 60 with --animation)")
+    ap.add_argument("--steps", type=int, default=0, help="timed frames (default 200: 0.28 s of rendering, so that the last frames' tails do not weigh on the mean; 60 with --animation)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--animation", type=int, default=0, metavar="F",
                     help="config 5: 256 spheres, 12 bounces, orbit cameras t = f/60 for f < F, a new camera every step")
@@ -334,7 +334,7 @@ def main():
     wl = WORKLOADS[workload]
     width, height, bounces = wl["width"], wl["height"], wl["bounces"]
     if args.steps <= 0:
-        args.steps = args.animation if args.animation > 0 else 20
+        args.steps = args.animation if args.animation > 0 else 200
     local = local % max(1, torch.cuda.device_count())  # rehearsals may put several ranks on one GPU
     if world > 1:
         if args.backend == "nccl":
