@@ -172,7 +172,15 @@ def compute_executed(profile, kernel_ms):
             "basis": profile["basis"], "source": profile["source"]}
 
 
-def other_configs(hip, host, torch, local, depth, tile_rows):
+def default_depth(workload, world=1):
+    """Frames in flight per GPU when --depth is not given: 3, and 2 for config 5 on one GPU -- its 256-thread workgroups (four per
+    CU, the plain rounds with patches) of three frames get in each other's way: 20.69 against 20.27 G path rays/s over 300 frames,
+    twice (profiles/r04/f_ab_log.txt); configs 2 / 3 / 4 are best with 3 (config 3: 34.74 against 33.84 with 2).  On several GPUs
+    the gather needs the third slot (see --depth)."""
+    return 2 if workload == "c5" and world == 1 else 3
+
+
+def other_configs(hip, host, torch, local, depth_given, tile_rows):
     """BASELINE configs 2, 4 (on one GPU) and 5 through the same calls and the same frames-in-flight loop as the headline, each
     frame checked against the hash the GENUINE reference produced for it (tests/golden/golden_full.json): what the driver sees
     of them.  Ray counts: the reference's own (golden_full.json) for the stills, the kernel's counting variant (untimed) for the
@@ -184,6 +192,7 @@ def other_configs(hip, host, torch, local, depth, tile_rows):
         scene = build_scene(name)
         cams = animation_cameras(w, h, frames) if frames else [scene.camera]
         t_setup = time.perf_counter()
+        depth = depth_given or default_depth(name)
         d = hip.Dist(local, scene, None, 0, 1, w, h, tile_rows=tile_rows, frames_in_flight=depth)
         setup_s = time.perf_counter() - t_setup
         try:
@@ -308,7 +317,7 @@ def main():
     ap.add_argument("--rccl-stand-in", action="store_true", help="TEST HOOK: bind the library TRT_RCCL_LIB names in RCCL's place "
                     "(tests/rccl_stub.cpp: several ranks on one GPU); without this flag the variable is ignored")
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
-    ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = the default, 3: the "
+    ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = the default: 3, and 2 for config 5 on one GPU: default_depth(); the "
                                                          "next frames' workgroups fill the CUs that a frame's tail leaves idle -- on one GPU "
                                                          "1.86 / 1.67 / 1.65 / 1.66 ms per frame with 1 / 2 / 3 / 4 -- and on several GPUs the "
                                                          "gather of frame f can only get on the machine when the persistent workgroups of frame "
@@ -328,9 +337,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    if args.depth <= 0:
-        args.depth = 3
+    auto_depth = args.depth <= 0
     workload = "c5" if args.animation > 0 else "c3"
+    if auto_depth:
+        args.depth = default_depth(workload, world)
     wl = WORKLOADS[workload]
     width, height, bounces = wl["width"], wl["height"], wl["bounces"]
     if args.steps <= 0:
@@ -634,7 +644,7 @@ def main():
             r.close()  # the headline's buffers make room
             r = None
             try:
-                out["configs"] = other_configs(hip, host, torch, local, args.depth, args.tile_rows)
+                out["configs"] = other_configs(hip, host, torch, local, 0 if auto_depth else args.depth, args.tile_rows)
             except Exception as e:  # never lose the headline over the rest
                 out["configs"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1:
