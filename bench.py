@@ -316,6 +316,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--rccl-stand-in", action="store_true", help="TEST HOOK: bind the library TRT_RCCL_LIB names in RCCL's place "
                     "(tests/rccl_stub.cpp: several ranks on one GPU); without this flag the variable is ignored")
+    ap.add_argument("--allow-fallback", action="store_true", help="if the product path (trt_dist_* behind the C-ABI) fails on any rank, time the "
+                    "PyTorch-level gather instead and say so in the line; WITHOUT this flag (the default) such a failure ends every rank with "
+                    "exit code 5 and the reason on stderr: a number for a path that is not the product is not a number")
     ap.add_argument("--check", action="store_true", help="rank 0 compares the assembled frame with a single-renderer frame (untimed)")
     ap.add_argument("--depth", type=int, default=0, help="frames in flight per GPU (1 = strictly one frame at a time; 0 = the default: 3, and 2 for config 5 on one GPU: default_depth(); the "
                                                          "next frames' workgroups fill the CUs that a frame's tail leaves idle -- on one GPU "
@@ -385,7 +388,8 @@ def main():
             uid = bytes(box.cpu().numpy().tobytes())
         # The library's communicator meets its peers here for the first time in the life of the process: create it and push one
         # frame through it on a side thread with a deadline, and let the ranks agree on the outcome.  If any rank failed (an
-        # error, or no frame within the deadline), every rank falls back to the PyTorch-level gather and the line says so.
+        # error, or no frame within the deadline), EVERY rank exits non-zero with the reason on stderr -- unless --allow-fallback
+        # was given: then every rank falls back to the PyTorch-level gather and the line says so.
         import threading
         problem = []
 
@@ -402,6 +406,9 @@ def main():
                 d.synchronize()
                 if rank == 0:
                     d.fetch(frame)
+                made["rccl_ranks"] = d.comm_ranks()  # what RCCL itself says of the communicator (ncclCommCount)
+                if world > 1 and made["rccl_ranks"] != world:
+                    raise RuntimeError(f"the communicator has {made['rccl_ranks']} ranks, WORLD_SIZE is {world}")
             except Exception as e:  # noqa: BLE001
                 problem.append(f"{type(e).__name__}: {e}")
 
@@ -426,9 +433,17 @@ def main():
             fetch = r.fetch
         else:
             fallback_reason = problem[0] if problem else "another rank failed"
-            print(f"bench: rank {rank}: C-ABI multi-GPU path unavailable ({fallback_reason}); falling back to the PyTorch-level gather", file=sys.stderr)
             if "dist" in made:
                 made["dist"].close()
+            if not args.allow_fallback:
+                # the product path failed: no line, no number.  Every rank has taken part in the agreement above, so every rank
+                # leaves here, in step, through the interpreter's normal exit (nothing is re-executed).
+                print(f"bench: rank {rank}: the C-ABI multi-GPU path (trt_dist_*) failed: {fallback_reason}; no fallback was allowed "
+                      "(--allow-fallback), giving up", file=sys.stderr, flush=True)
+                if world > 1:
+                    dist.destroy_process_group()
+                sys.exit(5)
+            print(f"bench: rank {rank}: C-ABI multi-GPU path unavailable ({fallback_reason}); falling back to the PyTorch-level gather", file=sys.stderr)
             r, contexts, rowset, render, fetch = torch_level_renderer()
     for c in contexts:
         c.set_kernel(args.kernel)
@@ -603,6 +618,8 @@ def main():
             "scene_tables": ctx0.scene_info(),
             "per_rank": per_rank,
             "rccl_library": hip.dist_rccl_library() if world > 1 and not rehearsal else None,
+            # the ranks of the communicator the product path created, as the library bound above reports them (ncclCommCount)
+            "rccl_ranks": made.get("rccl_ranks") if world > 1 and not rehearsal and fallback_reason is None else None,
             "rays_per_frame": {"path": path_mean, "shadow": float(np.mean(shadow_cam))},
             "all_rays_per_s": (path_timed + shadow_timed) / seconds,
             "frames_in_flight": args.depth,

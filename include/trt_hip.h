@@ -363,6 +363,9 @@ int trt_dist_fetch(trt_dist *d, const void *d_frame, Vector *pixels);
  * which rank r's shard starts at row r * max_rows.  Returns max_rows, the height every shard is padded to. */
 int trt_dist_source_rows(int width, int height, int tile_rows, int world, int *source_row);
 int trt_dist_info(const trt_dist *d, int *rank, int *world, int *local_rows, int *max_rows, int *frames_in_flight);
+/* How many ranks the communicator that was created has, as RCCL itself reports it (ncclCommCount; trt_dist_create fails unless
+ * it equals `world`): the record that "RCCL saw N ranks".  0 when no communicator exists (world == 1 without an id). */
+int trt_dist_comm_ranks(trt_dist *d);
 /* Diagnostics, averaged over the frame slots' most recent frames (synchronises): this rank's render time (render kernel + ordered
  * mean) and the time its part of the gather took on the communicator's stream (send, or the receives and the assembly kernel on
  * the root); 0 where there was nothing to measure.  One number pair per rank makes a multi-GPU run diagnosable from one line. */

@@ -87,7 +87,12 @@ int fail(int code, const char *fmt, ...)
             return fail(TRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int kCounterSlots = 40; // [path, shadow, rounds, phase-2 rounds, 24 stage stamps of the diagnostic build, swept, passes, loop diagnostics 30..36]
+#if defined(TRT_MARKS) && TRT_MARKS == 2
+constexpr int kCounterSlots = trt::kProfileAt + 64 * trt::kProfileKinds; // + the ISA profile's sums (tools/isa_profile.py)
+#else
+constexpr int kCounterSlots = 40;
+#endif
+// [path, shadow, rounds, phase-2 rounds, 24 stage stamps of the diagnostic build, swept, passes, loop diagnostics 30..36]
 constexpr int kEventRing = 256;
 constexpr double kPi = 3.14159265358979323846; // TRT.c:43
 
@@ -1508,6 +1513,13 @@ extern "C" int trt_read_counters(trt_context *ctx, unsigned long long *path_rays
         for (int i = 0; i < slots && total; i++)
             fprintf(stderr, "stamp %-16s %6.2f %%  %llu\n", names[i], 100.0 * c[4 + i] / total, c[4 + i]);
     }
+#if defined(TRT_MARKS) && TRT_MARKS == 2
+    if (getenv("TRT_PRINT_PROFILE"))
+        for (int k = 0; k < trt::kProfileKinds; k++)
+            for (int s = 0; s < 64; s++)
+                if (c[trt::kProfileAt + 64 * k + s])
+                    fprintf(stderr, "profile %d %d %llu\n", k, s, c[trt::kProfileAt + 64 * k + s]);
+#endif
     if (path_rays)
         *path_rays = c[0];
     if (shadow_rays)
@@ -1565,6 +1577,10 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
     f.tile_magic = (unsigned)std::min<unsigned long long>((0x100000000ull + (unsigned)rows->tile_rows - 1) / (unsigned)rows->tile_rows, 0xffffffffull);
     f.out = (double *)d_pixels;
     f.counters = ctx->counters_enabled ? ctx->d_counters.ptr : nullptr;
+#if defined(TRT_MARKS) && TRT_MARKS == 2
+    f.counters = ctx->d_counters.ptr; // the ISA profile of the SHIPPING instantiations lands there
+    HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long), lane_set ? ctx->alt_stream : ctx->stream));
+#endif
     f.queue = ctx->d_queue.ptr + 16 * lane_set; // a cache line apart
     f.width = rows->width;
     f.height = rows->height;
@@ -1734,7 +1750,11 @@ extern "C" int trt_render_host(trt_context *ctx, const Camera *camera, const trt
     const int local_rows = trt_rowset_rows(rows);
     const bool whole = rows->tile_first == 0 && rows->tile_step == 1 && rows->tile_rows >= rows->height;
     static const int band_count = getenv("TRT_HOST_BANDS") ? std::min(8, std::max(1, atoi(getenv("TRT_HOST_BANDS")))) : 4;
+#if defined(TRT_MARKS) && TRT_MARKS == 2
+    const int bands = 1; // the ISA profile is of ONE launch
+#else
     const int bands = whole && !ctx->counters_enabled && local_rows >= 256 && bytes >= (32u << 20) ? band_count : 1;
+#endif
     const int band_rows = (local_rows + bands - 1) / bands;
     const size_t row_bytes = (size_t)rows->width * sizeof(Vector);
     const int chunks_per_band = (int)std::min<size_t>(16 / bands, std::max<size_t>(1, (size_t)band_rows * row_bytes / (4u << 20)));

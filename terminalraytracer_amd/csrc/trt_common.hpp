@@ -44,6 +44,19 @@ constexpr int kPersistentBlock = TRT_BLOCK;
         stamp_sum[slot] += now_ - stamp_prev;                                                \
         stamp_prev = now_;                                                                   \
     } while (0)
+#elif defined(TRT_MARKS) && TRT_MARKS == 2
+// -DTRT_MARKS=2: the ISA PROFILE of the shipping kernels (tools/isa_profile.py, tools/build_isa_profile.sh).  A stage boundary
+// writes its number to m0 -- which these kernels do not use otherwise; the post-pass checks that -- and the post-pass adds, at
+// the head of every basic block, the block's instructions of every kind to lane m0 of one reserved VGPR per kind
+// (v_readlane / s_add / v_writelane; s100, s101 and v240... are outside what the kernels allocate).  No stamp sums in
+// SGPRs, no counting instantiation: the code profiled is the shipping instantiation's own, up to the scheduling barriers.
+#define TRT_STAMP_AT(slot)                                       \
+    do                                                           \
+    {                                                            \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        asm volatile("s_mov_b32 m0, %0 ; MARK" ::"n"(slot));     \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
 #elif defined(TRT_MARKS)
 // -DTRT_MARKS=1: the stage boundaries as comments in the compiler's assembly (tools/isa_stage_counts.py counts the
 // instructions between them); a scheduling barrier keeps each stage's instructions on its own side
@@ -60,6 +73,16 @@ constexpr int kPersistentBlock = TRT_BLOCK;
     {                      \
     } while (0)
 #endif
+// boundaries that only the ISA profile knows (the stamp builds keep their 24 slots)
+#if defined(TRT_MARKS) && TRT_MARKS == 2
+#define TRT_MARK_AT(slot) TRT_STAMP_AT(slot)
+#else
+#define TRT_MARK_AT(slot) \
+    do                    \
+    {                     \
+    } while (0)
+#endif
+constexpr int kProfileKinds = 11, kProfileAt = 40; // counters[kProfileAt + 64 kind + slot]: the ISA profile's sums
 
 // work units (single samples) fetched from the global queue per atomic; a returning atomic per request saturates
 // a single queue word (it cost 0.8 ms per frame before pooling)
@@ -94,7 +117,7 @@ struct CullView
     float cn, rm;
 };
 
-constexpr int kLdsCameraDoubles = 13;                       // basis x,y,z (9) eye (3) -screen_distance (1)
+constexpr int kLdsCameraDoubles = 16;                       // basis x,y,z (9) eye (3) -screen_distance (1) basis z * -screen_distance (3)
 constexpr int kDirGridDoubles = 14, kPointGridDoubles = 9;  // sizeof(trt_dirgrid) / 8, sizeof(trt_pointgrid) / 8 (asserted in trt_rounds.hpp)
 
 // TRT.c:1063-1066 for frames rendered with samples as work units: pixel = (((0 + s0) + s1) + ...) * (1/spp),

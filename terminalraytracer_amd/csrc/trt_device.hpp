@@ -40,6 +40,16 @@ TRT_DEV d3 scale(d3 a, double s) { return d3{a.x * s, a.y * s, a.z * s}; }
 #define TRT_LEAN_MATH 1
 #endif
 
+// the short ways below are the ones taken: say so, so that they are laid out as the fall-through (two taken branches fewer each)
+#ifndef TRT_OPT_LIKELY
+#define TRT_OPT_LIKELY 1
+#endif
+#if TRT_OPT_LIKELY
+#define TRT_LIKELY(c) __builtin_expect(!!(c), 1)
+#else
+#define TRT_LIKELY(c) (c)
+#endif
+
 TRT_DEV unsigned hi32(double x) { return (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32); }
 TRT_DEV unsigned lo32(double x) { return (unsigned)__builtin_bit_cast(unsigned long long, x); }
 
@@ -52,7 +62,7 @@ TRT_DEV bool mid_range(double x) { return hi32(x) - (723u << 20) < (600u << 20);
 TRT_DEV double sqrt_exact(double x) // == __builtin_sqrt(x)
 {
 #if TRT_LEAN_MATH && TRT_LEAN_SQRT
-    if (!__any(!mid_range(x)))
+    if (TRT_LIKELY(!__any(!mid_range(x))))
     { // the steps of the compiler's expansion between its scaling and its 0/inf select
         const double y = __builtin_amdgcn_rsq(x);
         double g = x * y, h = y * 0.5;
@@ -72,7 +82,12 @@ TRT_DEV double sqrt_exact(double x) // == __builtin_sqrt(x)
 #ifndef TRT_LEAN_UNIT
 #define TRT_LEAN_UNIT 2
 #endif
-TRT_DEV d3 unit(d3 a)
+// `is_unit` (out): the result is KNOWN to be a unit vector to within 12u -- far inside the |d.d - 1| <= 2^-40 the candidate
+// tables ask of a ray (trt_lightgrid.h, trt_raygrid.h) -- because it was divided by its length and nothing left the normal range:
+// len = |a| (1 +- 2u) (the sum of squares of components that are zero or >= 2^-300 rounds three times, the root once),
+// every quotient is a_k / len (1 +- u), so sum q_k^2 = 1 +- 8u, and forming that sum adds 3u.  false says nothing (the caller
+// then tests d.d itself).  Saves the callers five FP64 operations and a compare per ray.
+TRT_DEV d3 unit(d3 a, bool &is_unit)
 {
     const double len = sqrt_exact(a.x * a.x + a.y * a.y + a.z * a.z);
 #if TRT_LEAN_MATH && TRT_LEAN_UNIT == 2
@@ -87,7 +102,8 @@ TRT_DEV d3 unit(d3 a)
     int lo = ex < ey ? ex : ey;
     lo = lo < ez ? lo : ez;
     const bool ok = len < 0x1p300 && lo > -300;
-    if (!__any(!ok))
+    is_unit = longer && ok;
+    if (TRT_LIKELY(!__any(!ok)))
     {
         const double den = longer ? len : 1.0;
         double r = __builtin_amdgcn_rcp(den);
@@ -115,6 +131,7 @@ TRT_DEV d3 unit(d3 a)
     }
     return a;
 #else
+    is_unit = false;
     if (len > 0.0001)
     {
 #if TRT_LEAN_MATH
@@ -150,6 +167,12 @@ TRT_DEV d3 unit(d3 a)
     }
     return a;
 #endif
+}
+
+TRT_DEV d3 unit(d3 a)
+{
+    bool ignored;
+    return unit(a, ignored);
 }
 
 // the compiler's own expansions, for trt_selftest_unit

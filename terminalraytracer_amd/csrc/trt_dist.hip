@@ -50,7 +50,7 @@ int dist_fail(int code, const char *fmt, ...)
             return dist_fail(TRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-// the eight RCCL entry points used, bound by name
+// the nine RCCL entry points used, bound by name
 struct Rccl
 {
     void *handle = nullptr;
@@ -62,6 +62,7 @@ struct Rccl
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     char why[256] = "";
 };
 
@@ -72,8 +73,10 @@ struct Rccl
 // RCCL itself.  trt_dist_rccl_library() says which library was bound.
 Rccl g_rccl; // written inside the call_once below, read-only afterwards
 std::atomic<int> g_override_allowed{0};
-std::atomic<int> g_bind_started{0};
-char g_bound_name[512] = ""; // written inside the call_once, read-only afterwards
+std::atomic<int> g_bind_started{0};  // the call_once has begun: the override can no longer be allowed or withdrawn
+std::atomic<int> g_name_published{0}; // ... and g_bound_name is complete (set with release after the name is written: a rank may be a thread)
+char g_bound_name[512] = "";          // written inside the call_once before g_name_published, read-only afterwards
+const char *bound_name() { return g_name_published.load(std::memory_order_acquire) ? g_bound_name : ""; }
 
 Rccl *rccl()
 {
@@ -92,6 +95,7 @@ Rccl *rccl()
             if (handle)
                 snprintf(g_bound_name, sizeof g_bound_name, "%s%s", override_name && *override_name ? "STAND-IN (TRT_RCCL_LIB): " : "", names[i]);
         }
+        g_name_published.store(1, std::memory_order_release); // "" if nothing could be loaded
         if (!handle)
         {
             const char *why = dlerror();
@@ -112,6 +116,7 @@ Rccl *rccl()
         lib.Send = (decltype(lib.Send))bind("ncclSend");
         lib.Recv = (decltype(lib.Recv))bind("ncclRecv");
         lib.GetErrorString = (decltype(lib.GetErrorString))bind("ncclGetErrorString");
+        lib.CommCount = (decltype(lib.CommCount))bind("ncclCommCount");
         if (!ok)
         {
             snprintf(lib.why, sizeof lib.why, "the RCCL library lacks an entry point");
@@ -181,6 +186,7 @@ struct trt_dist
     int *d_source_row = nullptr; // root: frame row -> row of the gather buffer
     bool through_comm = false;   // world > 1, or world == 1 with an id given: the gather path is taken (with no peers to receive from)
     bool rgb8 = false;           // byte buffers allocated (trt_dist_enable_rgb8)
+    int comm_ranks = 0;          // what ncclCommCount says of the communicator that was created (0: none, the gather path is not taken)
     bool poisoned = false;       // a collective failed on this rank: its peers may have gone on without it, nothing can be trusted any more
     long calls = 0;
 };
@@ -190,12 +196,12 @@ extern "C" const char *trt_dist_last_error(void) { return g_dist_error; }
 extern "C" int trt_dist_allow_rccl_override(int allow)
 {
     if (g_bind_started.load())
-        return dist_fail(TRT_ERR_NOT_INITIALISED, "RCCL has been bound already (%s): the override must be allowed before the first use", g_bound_name);
+        return dist_fail(TRT_ERR_NOT_INITIALISED, "RCCL has been bound already (%s): the override must be allowed before the first use", bound_name());
     g_override_allowed.store(allow ? 1 : 0);
     return TRT_OK;
 }
 
-extern "C" const char *trt_dist_rccl_library(void) { return g_bind_started.load() ? g_bound_name : ""; }
+extern "C" const char *trt_dist_rccl_library(void) { return bound_name(); }
 
 // The root's assembly map (pure host arithmetic, no GPU): frame row -> row of the rank-major gather buffer in which rank r's
 // shard starts at row r * max_rows.  Returns max_rows (the padded shard height), or a negative TRT_ERR_*.
@@ -241,6 +247,13 @@ extern "C" int trt_dist_unique_id(void *id_out)
     DIST_NCCL(R, R->GetUniqueId(&id));
     memcpy(id_out, &id, sizeof id);
     return TRT_OK;
+}
+
+extern "C" int trt_dist_comm_ranks(trt_dist *d)
+{
+    if (!d)
+        return dist_fail(TRT_ERR_ARGUMENT, "d is NULL");
+    return d->comm_ranks;
 }
 
 extern "C" int trt_dist_destroy(trt_dist *d)
@@ -378,6 +391,10 @@ extern "C" int trt_dist_create(int device, const Scene *scene, const void *id, i
         const ncclResult_t r = R->CommInitRank(&d->comm, world, uid, rank);
         if (r != ncclSuccess)
             return bail(dist_fail(TRT_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, R->GetErrorString(r)));
+        // what the library itself says of the communicator: a record of "RCCL saw N ranks" for the caller (trt_dist_comm_ranks)
+        const ncclResult_t rc = R->CommCount(d->comm, &d->comm_ranks);
+        if (rc != ncclSuccess || d->comm_ranks != world)
+            return bail(dist_fail(TRT_ERR_HIP, "the communicator has %d ranks, %d were asked for (%s)", d->comm_ranks, world, R->GetErrorString(rc)));
         if (rank == d->root)
         { // frame row -> row of the rank-major gather buffer (the tile map of trt_rowset_frame_row)
             std::vector<int> source((size_t)height, -1);

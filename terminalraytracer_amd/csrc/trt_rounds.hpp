@@ -38,6 +38,20 @@
 #include "trt_raygrid.h"
 #include "trt_common.hpp"
 
+// A/B switches of round 5's instruction-level changes (profiles/r05/f_ab_log.txt); 1 = as shipped unless noted
+#ifndef TRT_OPT_DIRCONST
+#define TRT_OPT_DIRCONST 1
+#endif
+#ifndef TRT_OPT_UNITFLAG
+#define TRT_OPT_UNITFLAG 0 // unit()'s "known to be of length 1" instead of testing d.d: 1 path rays, 2 point-light shadow rays, 3 both, 4 branch-free (measured SLOWER)
+#endif
+#ifndef TRT_OPT_POOLCHECK
+#define TRT_OPT_POOLCHECK 1 // the exact loops ask the lanes for a pool word only in the iterations that can need one
+#endif
+#ifndef TRT_OPT_BZSZ
+#define TRT_OPT_BZSZ 1
+#endif
+
 namespace trt
 {
 
@@ -72,6 +86,8 @@ struct GridView
 static_assert(sizeof(trt_rayfamily) == 8 * TRT_RAYFAMILY_DOUBLES, "families of the eye in the LDS image");
 static_assert(sizeof(trt_dirgrid) == 8 * kDirGridDoubles && sizeof(trt_pointgrid) == 8 * kPointGridDoubles, "light-table headers in the LDS image");
 
+constexpr int kDirRecord = 8; // doubles per directional light in the LDS image
+
 struct LdsImage
 {
     const float4 *cull;  // culling table {Cx,Cy,Cz,kk}
@@ -79,7 +95,8 @@ struct LdsImage
     const double *sph;   // per sphere {cx, cy, cz, r^2}: one 32-byte record, 16-byte aligned, read with two ds_read_b128 by the exact
                          // test (measured 1.9 % faster than four ds_read_b64 from a structure of arrays)
     const double *mat;   // (n+2) x {colour, reflectivity, specularity}: spheres, ground even, ground odd
-    const double *dir;   // per directional light: unit to-light (3), colour (3)
+    const double *dir;   // per directional light (kDirRecord doubles): unit to-light (3), colour (3), then what every shadow ray towards it shares:
+                         // a = d.d (TRT.c:643) and d.n of the ground test (TRT.c:679), formed once per workgroup from the same operands
     const double *pt;    // per point light: position (3), colour (3), intensity
     const double *b255;  // byte / 255.0
     const double *cam;   // basis x,y,z (9), eye (3), -screen_distance
@@ -99,7 +116,7 @@ struct LdsImage
 inline size_t rounds_lds_bytes(const SceneView &s, int spp, int patches)
 {
     const size_t padded = ((size_t)s.num_spheres + kCullGroup - 1) / kCullGroup * kCullGroup;
-    return sizeof(double) * (padded * 2 + (size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * 6 +
+    return sizeof(double) * (padded * 2 + (size_t)s.num_spheres * 4 + ((size_t)s.num_spheres + 2) * 5 + (size_t)s.num_dir * kDirRecord +
                              (size_t)s.num_point * 7 + 256 + kLdsCameraDoubles + 2 * (size_t)spp + 1 /* 16-B alignment */ +
                              (size_t)s.num_dir * padded * 2 + (size_t)s.num_dir * kDirGridDoubles + (size_t)s.num_point * kPointGridDoubles +
                              (size_t)s.num_spheres * 4 + 2 * TRT_RAYFAMILY_DOUBLES + (size_t)patches * TRT_PATCH_RECORD);
@@ -110,7 +127,7 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
     const int n = s.num_spheres, nd = s.num_dir, np = s.num_point;
     float4 *l_cull = (float4 *)lds;
     double *l_sph = lds + cull.padded * 2; // 16-byte aligned: the culling table before it is whole float4s
-    double *l_mat = l_sph + 4 * n, *l_dir = l_mat + (n + 2) * 5, *l_pt = l_dir + nd * 6, *l_255 = l_pt + np * 7;
+    double *l_mat = l_sph + 4 * n, *l_dir = l_mat + (n + 2) * 5, *l_pt = l_dir + nd * kDirRecord, *l_255 = l_pt + np * 7;
     double *l_cam = l_255 + 256, *l_jit = l_cam + kLdsCameraDoubles;
     for (int i = threadIdx.x; i < cull.padded; i += blockDim.x)
         l_cull[i] = ((const float4 *)cull.table)[i];
@@ -130,8 +147,10 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
     {
         const double *li = s.dir_lights + i * kDirLightDoubles;
         const d3 tl = unit(scale(load3(li), -1.0)); // TRT.c:903-904, the same value for every hit point
-        l_dir[i * 6 + 0] = tl.x, l_dir[i * 6 + 1] = tl.y, l_dir[i * 6 + 2] = tl.z;
-        l_dir[i * 6 + 3] = li[3], l_dir[i * 6 + 4] = li[4], l_dir[i * 6 + 5] = li[5];
+        l_dir[i * kDirRecord + 0] = tl.x, l_dir[i * kDirRecord + 1] = tl.y, l_dir[i * kDirRecord + 2] = tl.z;
+        l_dir[i * kDirRecord + 3] = li[3], l_dir[i * kDirRecord + 4] = li[4], l_dir[i * kDirRecord + 5] = li[5];
+        l_dir[i * kDirRecord + 6] = dot(tl, tl);                     // a of ray_intersects_sphere (TRT.c:643) for every shadow ray towards this light
+        l_dir[i * kDirRecord + 7] = dot(tl, load3(s.ground + 3)); // d.n of ray_intersects_plane (TRT.c:679)
     }
     for (int i = threadIdx.x; i < np * 7; i += blockDim.x)
         l_pt[i] = s.point_lights[i];
@@ -139,8 +158,10 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
         l_255[i] = (double)i / 255.0; // TRT.c:866
     for (int i = threadIdx.x; i < 12; i += blockDim.x)
         l_cam[i] = f.cam[i];
+    if (threadIdx.x < 3) // TRT.c:989, :1000-1002: basis z scaled by sz = -screen_distance, the same product for every primary ray
+        l_cam[13 + threadIdx.x] = f.cam[6 + threadIdx.x] * -f.cam[12];
     if (threadIdx.x == 0)
-        l_cam[12] = -f.cam[12]; // TRT.c:989
+        l_cam[12] = -f.cam[12];
     for (int i = threadIdx.x; i < 2 * f.spp; i += blockDim.x)
         l_jit[i] = f.jitter[i];
     // fixed-direction tables behind everything else, on a 16-byte boundary (all offsets above are whole doubles)
@@ -151,7 +172,7 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
     {
         const int li = i / cull.padded, j = i - li * cull.padded;
         const float4 e = l_cull[j];
-        const float dx = (float)l_dir[li * 6 + 0], dy = (float)l_dir[li * 6 + 1], dz = (float)l_dir[li * 6 + 2]; // = trt_filter_setup's d
+        const float dx = (float)l_dir[li * kDirRecord + 0], dy = (float)l_dir[li * kDirRecord + 1], dz = (float)l_dir[li * kDirRecord + 2]; // = trt_filter_setup's d
         l_cull_dir[i] = float4{e.x, e.y, e.z, trt_filter_fixed_dir_kk(e.x, e.y, e.z, e.w, dx, dy, dz)};
     }
     // headers of the light-space tables behind the fixed-direction tables (whole doubles again: 4 floats per entry)
@@ -181,7 +202,7 @@ TRT_DEV LdsImage stage_lds_image(double *lds, const SceneView &s, const CullView
     {
         for (int i = threadIdx.x; i < nd; i += blockDim.x)
         {
-            const d3 sd = load3(l_dir + i * 6);
+            const d3 sd = load3(l_dir + i * kDirRecord);
             if (!(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13))
                 ((trt_dirgrid *)l_dirgrid)[i].rg2 = -1.0f;
         }
@@ -263,9 +284,10 @@ TRT_DEV bool exact_step(const LdsImage &L, d3 o, d3 d, double a, int i, bool val
 #endif
 
 
-template <bool ANY_HIT, bool REFRACT = false>
+template <bool ANY_HIT, bool REFRACT = false, int MARK_BASE = 0>
 TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bool active, d3 gp, d3 gn, unsigned &phase2_rounds, unsigned &lane_tests,
-                  const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool, int list_bits, int inside = -1
+                  const float4 *fixed, bool use_list, unsigned long long cell, const unsigned long long *pool, int list_bits, int inside = -1,
+                  const double *shared_ad = nullptr // every lane's ray has the SAME direction (a directional light's shadow rays): {d.d, d.gn} from the LDS image
 #if TRT_STAMP
                   ,
                   unsigned long long *stamp_sum = nullptr, unsigned long long *stamp_prev_p = nullptr, int stamp_base = 0
@@ -275,6 +297,8 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
 #if TRT_STAMP
     unsigned long long &stamp_prev = *stamp_prev_p;
 #define TRT_TRACE_STAMP(k) TRT_STAMP_AT(stamp_base + (k))
+#elif defined(TRT_MARKS) && TRT_MARKS == 2
+#define TRT_TRACE_STAMP(k) TRT_STAMP_AT(MARK_BASE + (k)) // MARK_BASE: the call site's slots (a template parameter: an immediate)
 #elif defined(TRT_MARKS)
 #define TRT_TRACE_STAMP(k) TRT_STAMP_AT(trace_##k)
 #else
@@ -289,7 +313,9 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     best.p = o;
     best.i = -1;
     best.t = 0.0;
-    const double a = dot(d, d);
+    if (!TRT_OPT_DIRCONST)
+        shared_ad = nullptr;
+    const double a = shared_ad ? shared_ad[0] : dot(d, d);
     if (use_list)
     {
         const unsigned ctl = (unsigned)(cell >> 56);
@@ -318,6 +344,9 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
             for (int j = 0; __any(j < count); j++)
             {
                 const bool valid = j < count;
+#if TRT_OPT_POOLCHECK
+                if ((j & per_mask) == 0)
+#endif
                 if (__any(valid && pooled && (j & per_mask) == 0))
                     if (valid && pooled && (j & per_mask) == 0)
                         word = pool[at + ((unsigned)j >> per_shift)];
@@ -355,6 +384,9 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
             phase2_rounds++;
             const bool valid = k < count;
             lane_tests += valid;
+#if TRT_OPT_POOLCHECK
+            if ((k & per_mask) == 0) // k is the wave's: seven iterations of eight ask nothing of the lanes
+#endif
             if (__any(valid && pooled && (k & per_mask) == 0))
                 if (valid && pooled && (k & per_mask) == 0)
                     cur = pool[at + ((unsigned)k >> per_shift)];
@@ -427,7 +459,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     // selects: a ray can only hit if |d.n| > 1e-5 and numerator and denominator of t have the same sign (opposite signs: t <= 0,
     // whatever the quotient's digits are), so a wave whose rays all head away from the plane skips the division.
     {
-        const double denom = dot(d, gn), num = dot(sub(gp, o), gn);
+        const double denom = shared_ad ? shared_ad[1] : dot(d, gn), num = dot(sub(gp, o), gn);
         const bool maybe = active && !(ANY_HIT && best.i >= 0) && __builtin_fabs(denom) > 0.00001 &&
                            (long long)(__builtin_bit_cast(unsigned long long, num) ^ __builtin_bit_cast(unsigned long long, denom)) >= 0;
         if (__any(maybe))
@@ -480,6 +512,9 @@ TRT_DEV void point_light_search(const LdsImage &L, int n, d3 o, d3 d, bool activ
         rounds++;
         const bool valid = k < count;
         lane_tests += valid;
+#if TRT_OPT_POOLCHECK
+        if ((k & per_mask) == 0)
+#endif
         if (__any(valid && pooled && (k & per_mask) == 0))
             if (valid && pooled && (k & per_mask) == 0)
                 cur = pool[at + ((unsigned)k >> per_shift)];
@@ -523,7 +558,21 @@ TRT_DEV void point_light_search(const LdsImage &L, int n, d3 o, d3 d, bool activ
 // expected in (0 eye, 1 mirror eye, 2 + i sphere i, 2 + n + i mirror sphere i, < 0 none).  `fallback` is set for an active lane
 // whose ray fails the family's membership test (its line must pass within r_chk of the apex, its origin not more than r_chk
 // behind it, within the table's range; a unit direction) or whose cell has no list: the caller then sweeps.
-TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n, int fam, d3 o, d3 d, bool active, bool &fallback)
+// `d_unit`: d is known to be a unit vector (unit()'s flag); a lane without that knowledge makes its wave test d.d.
+template <int WHICH>
+TRT_DEV bool unit_direction(d3 d, bool active, bool d_unit)
+{
+    bool ok = d_unit;
+    if (!(TRT_OPT_UNITFLAG & WHICH) && TRT_OPT_UNITFLAG != 4)
+        return __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
+    if (TRT_OPT_UNITFLAG == 4)
+        return d_unit; // experiment only: no fall-back test at all (a ray whose direction unit() left alone makes its wave sweep)
+    if (__any(active && !d_unit))
+        ok = d_unit || __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
+    return ok;
+}
+
+TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n, int fam, d3 o, d3 d, bool active, bool &fallback, bool d_unit = false)
 {
     const bool has = active && fam >= 0;
     const int f = has ? fam : 0;
@@ -544,7 +593,7 @@ TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n
     const d3 w = sub(o, apex);
     const d3 c = d3{w.y * d.z - w.z * d.y, w.z * d.x - w.x * d.z, w.x * d.y - w.y * d.x};
     const bool near_line = dot(c, c) <= r_chk * r_chk, ahead = dot(w, d) >= -r_chk, in_range = dot(w, w) <= rg2;
-    const bool unit_dir = __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
+    const bool unit_dir = unit_direction<1>(d, active, d_unit);
     const bool member = near_line & ahead & in_range & unit_dir;
     const int g = of_eye ? G.g_eye : G.g_sph;
     const int at = trt_cubemap_cell((float)d.x, (float)d.y, (float)d.z, 0.5f * (float)g, (float)(g - 1), g);
@@ -565,7 +614,7 @@ TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n
 // from the ground cannot hit the ground again).  `fallback` is set for an active lane whose ray fails the family's
 // membership test (its line must pass within r_chk of the apex, its origin not more than r_chk behind it, within the table's
 // range; a unit direction) or whose cell has no list: the caller then sweeps.
-TRT_DEV unsigned long long path_cell_patches(const LdsImage &L, const GridView &G, int n, int &fam, d3 o, d3 d, bool active, bool &fallback)
+TRT_DEV unsigned long long path_cell_patches(const LdsImage &L, const GridView &G, int n, int &fam, d3 o, d3 d, bool active, bool &fallback, bool d_unit = false)
 {
     const bool has = active && fam >= 0;
     const int f = has ? fam : 0;
@@ -599,7 +648,7 @@ TRT_DEV unsigned long long path_cell_patches(const LdsImage &L, const GridView &
     const d3 w = sub(o, apex);
     const d3 c = d3{w.y * d.z - w.z * d.y, w.z * d.x - w.x * d.z, w.x * d.y - w.y * d.x};
     const bool near_line = dot(c, c) <= r_chk * r_chk, ahead = dot(w, d) >= -r_chk, in_range = dot(w, w) <= rg2;
-    const bool unit_dir = __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
+    const bool unit_dir = unit_direction<1>(d, active, d_unit);
     const bool member = near_line & ahead & in_range & unit_dir;
     const int g = of_eye ? G.g_eye : G.g_sph;
     const int at = trt_cubemap_cell((float)d.x, (float)d.y, (float)d.z, 0.5f * (float)g, (float)(g - 1), g);
@@ -656,7 +705,7 @@ struct PathHit
 // does, it has no family).
 template <bool COUNT, bool REFRACT = false, bool PATCHES = false>
 TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridView &grids, int n, d3 o, d3 d, int &fam, bool alive, d3 gp, d3 gn,
-                           Tally &tally, int inside = -1)
+                           Tally &tally, int inside = -1, bool d_unit = false)
 {
     TRT_STAGE_STAMPS(tally);
     bool p_list = false;
@@ -665,19 +714,19 @@ TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridVi
     {
         bool fallback;
         if constexpr (PATCHES)
-            p_cell = path_cell_patches(L, grids, n, fam, o, d, alive, fallback); // fam: now what a reflection by the ground belongs to
+            p_cell = path_cell_patches(L, grids, n, fam, o, d, alive, fallback, d_unit); // fam: now what a reflection by the ground belongs to
         else
-            p_cell = path_cell(L, grids, n, fam, o, d, alive, fallback);
+            p_cell = path_cell(L, grids, n, fam, o, d, alive, fallback, d_unit);
         p_list = !__any(fallback);
     }
     if (COUNT && !p_list)
         tally.swept++;
     PathHit r;
 #if TRT_STAMP
-    r.ph = trace<false, REFRACT>(L, cull, n, o, d, alive, gp, gn, tally.iters[0], tally.tests[0], nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside, stamp_sum,
+    r.ph = trace<false, REFRACT>(L, cull, n, o, d, alive, gp, gn, tally.iters[0], tally.tests[0], nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside, nullptr, stamp_sum,
                                  &stamp_prev, 2);
 #else
-    r.ph = trace<false, REFRACT>(L, cull, n, o, d, alive, gp, gn, tally.iters[0], tally.tests[0], nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside);
+    r.ph = trace<false, REFRACT, 2>(L, cull, n, o, d, alive, gp, gn, tally.iters[0], tally.tests[0], nullptr, p_list, p_cell, grids.pool, grids.list_bits, inside);
 #endif
     r.hit = alive && r.ph.i >= 0;
     r.sky = alive && r.ph.i < 0;
@@ -722,8 +771,9 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
         double factor;
         if (li < nd)
         { // directional light, TRT.c:900-923
-            sd = load3(L.dir + li * 6);
-            lcolor = load3(L.dir + li * 6 + 3);
+            TRT_MARK_AT(24); // ISA profile: a directional light's pass starts
+            sd = load3(L.dir + li * kDirRecord);
+            lcolor = load3(L.dir + li * kDirRecord + 3);
             bool use_list = false;
             unsigned long long cell = 0;
             if (grids.enabled)
@@ -740,9 +790,10 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
             TRT_STAMP_AT(8); // look-up
 #if TRT_STAMP
             const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[1], tally.tests[1], L.cull_dir + li * cull.padded, use_list, cell, grids.pool,
-                                       grids.list_bits, -1, stamp_sum, &stamp_prev, 9);
+                                       grids.list_bits, -1, L.dir + li * kDirRecord + 6, stamp_sum, &stamp_prev, 9);
 #else
-            const Hit sh = trace<true>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[1], tally.tests[1], L.cull_dir + li * cull.padded, use_list, cell, grids.pool, grids.list_bits);
+            const Hit sh = trace<true, false, 9>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[1], tally.tests[1], L.cull_dir + li * cull.padded, use_list, cell, grids.pool, grids.list_bits,
+                                                 -1, L.dir + li * kDirRecord + 6);
 #endif
             is_lit = sh.i < 0;
             factor = min1(dot(normal, sd));
@@ -750,11 +801,13 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
         }
         else
         { // point light, TRT.c:926-957
+            TRT_MARK_AT(25); // ISA profile: a point light's pass starts
             const double *pl = L.pt + (li - nd) * 7;
             const d3 to_light = sub(load3(pl), o);
             const double light_d2 = dot(to_light, to_light);
             const double strength = clampd(pl[6] / light_d2, 0.0, 1.0);
-            sd = unit(to_light);
+            bool sd_unit;
+            sd = unit(to_light, sd_unit);
             lcolor = load3(pl + 3);
             bool use_list = false;
             unsigned long long cell = 0;
@@ -763,7 +816,7 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
                 const trt_pointgrid *G = L.pointgrid + (li - nd);
                 int far;
                 const int c = trt_pointgrid_cell(G, o.x, o.y, o.z, &far);
-                far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
+                far |= !unit_direction<2>(sd, lit_lanes, sd_unit);
                 if (lit_lanes && !far)
                     cell = grids.point_lists[(size_t)(li - nd) * grids.point_stride + (unsigned)c];
                 use_list = !__any(lit_lanes && (far || (unsigned)(cell >> 56) == TRT_LIST_NONE));
@@ -792,9 +845,9 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
                 if (COUNT)
                     tally.full++;
 #if TRT_STAMP
-                const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[2], tally.tests[2], nullptr, use_list, cell, grids.pool, grids.list_bits, -1, stamp_sum, &stamp_prev, 15);
+                const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[2], tally.tests[2], nullptr, use_list, cell, grids.pool, grids.list_bits, -1, nullptr, stamp_sum, &stamp_prev, 15);
 #else
-                const Hit sh = trace<false>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[2], tally.tests[2], nullptr, use_list, cell, grids.pool, grids.list_bits);
+                const Hit sh = trace<false, false, 26>(L, cull, n, o, sd, lit_lanes, gp, gn, tally.iters[2], tally.tests[2], nullptr, use_list, cell, grids.pool, grids.list_bits);
 #endif
                 is_lit = sh.i < 0;
                 // A blocker: is it farther than the light?  The reference compares light_d2 with the squared distance to the
@@ -1043,7 +1096,11 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
                         d3 dir = d3{0.0, 0.0, 0.0};
                         dir = add(dir, scale(load3(L.cam + 0), sx));
                         dir = add(dir, scale(load3(L.cam + 3), sy));
+#if TRT_OPT_BZSZ
+                        dir = add(dir, load3(L.cam + 13)); // scale(basis z, sz), formed once per workgroup (stage_lds_image)
+#else
                         dir = add(dir, scale(load3(L.cam + 6), L.cam[12]));
+#endif
                         next_dir = sub(dir, load3(L.cam + 9)); // sic, TRT.c:1005
                         o = load3(L.cam + 9);
                         fam = 0;
@@ -1062,7 +1119,8 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         if (COUNT)
             tally.rounds++;
         TRT_STAMP_AT(0); // units + primary rays
-        d = unit(next_dir); // TRT.c:1008 for a primary ray, TRT.c:1055 for a reflected one
+        bool d_unit;
+        d = unit(next_dir, d_unit); // TRT.c:1008 for a primary ray, TRT.c:1055 for a reflected one; d_unit: known to be of length 1
 
         // ======================================= P: the path ray =======================================
         if (COUNT && alive)
@@ -1071,7 +1129,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         PathHit hit;
         {
             TRT_FRESH_ARGS;
-            hit = path_stage<COUNT, REFRACT, PATCHES>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside);
+            hit = path_stage<COUNT, REFRACT, PATCHES>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside, d_unit);
         }
         if constexpr (COMPACT)
         {
@@ -1309,6 +1367,22 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         TRT_STAMP_AT(21); // END of the bounce
     }
 
+#if defined(TRT_MARKS) && TRT_MARKS == 2
+    // ISA profile (tools/isa_profile.py): lane `slot` of v240 + kind holds the wave's executed instructions of that kind in
+    // the intervals that START at stage boundary `slot` (63: before the first boundary)
+    if (!COUNT && f.counters)
+    {
+#define TRT_PROFILE_DUMP(kind)                                                         \
+    {                                                                                  \
+        unsigned x_;                                                                   \
+        asm volatile("v_mov_b32 %0, v" #kind : "=v"(x_));                              \
+        atomicAdd(&f.counters[kProfileAt + 64 * ((kind) - 240) + lane], (unsigned long long)x_); \
+    }
+        TRT_PROFILE_DUMP(240) TRT_PROFILE_DUMP(241) TRT_PROFILE_DUMP(242) TRT_PROFILE_DUMP(243) TRT_PROFILE_DUMP(244) TRT_PROFILE_DUMP(245)
+        TRT_PROFILE_DUMP(246) TRT_PROFILE_DUMP(247) TRT_PROFILE_DUMP(248) TRT_PROFILE_DUMP(249) TRT_PROFILE_DUMP(250)
+#undef TRT_PROFILE_DUMP
+    }
+#endif
     if (COUNT && f.counters)
     {
         atomicAdd(&f.counters[0], (unsigned long long)tally.path);

@@ -103,6 +103,7 @@ SYMBOLS = {
     "trt_dist_frame_times": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "trt_dist_allow_rccl_override": (_I, [_I]),
     "trt_dist_rccl_library": (C.c_char_p, []),
+    "trt_dist_comm_ranks": (_I, [_VP]),
     "trt_dist_create": (_I, [_I, C.POINTER(L.Scene), _VP, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_VP)]),
     "trt_dist_set_scene": (_I, [_VP, C.POINTER(L.Scene)]),
     "trt_dist_render": (_I, [_VP, C.POINTER(L.Camera), _I, _I, C.POINTER(_VP)]),
@@ -514,6 +515,13 @@ class Dist:
         """another scene for every frame slot: the first slot builds its tables, the others share them (trt_dist_set_scene)"""
         scene = scene_data.as_scene()
         _dist_check(lib().trt_dist_set_scene(self._h, C.byref(scene)))
+
+    def comm_ranks(self):
+        """ranks of the communicator as RCCL reports them (ncclCommCount); 0 without a communicator (trt_dist_comm_ranks)"""
+        n = lib().trt_dist_comm_ranks(self._h)
+        if n < 0:
+            _dist_check(n)
+        return n
 
     def frame_times(self):
         """(render_ms, gather_ms) of this rank, averaged over the slots' most recent frames (trt_dist_frame_times)"""

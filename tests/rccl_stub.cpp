@@ -320,6 +320,14 @@ extern "C" ncclResult_t ncclCommDestroy(ncclComm_t c)
     return failed ? ncclSystemError : ncclSuccess;
 }
 
+extern "C" ncclResult_t ncclCommCount(const ncclComm_t c, int *count)
+{
+    if (!c || !count)
+        return ncclInvalidArgument;
+    *count = c->shared->arrived.load(); // the ranks that actually met in ncclCommInitRank
+    return ncclSuccess;
+}
+
 extern "C" ncclResult_t ncclGroupStart(void) { return ncclSuccess; }
 extern "C" ncclResult_t ncclGroupEnd(void) { return ncclSuccess; }
 

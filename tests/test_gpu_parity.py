@@ -563,6 +563,26 @@ def test_bench_two_ranks_through_the_c_abi_on_one_gpu():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["verified"] is True and "trt_dist_*" in line["config"]["multi_gpu_path"] and \
         "STAND-IN" in line["config"]["multi_gpu_path"], line["config"]
+    assert line["rccl_ranks"] == 2 and "STAND-IN" in line["rccl_library"], (line["rccl_ranks"], line["rccl_library"])  # the communicator's own count
+
+    # a product path that fails must fail the bench: no line, a non-zero exit code and the reason on stderr ...
+    def run(extra, fail):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                               "--master-port", str(port), os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rccl-stand-in",
+                               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-verify"] + extra, capture_output=True, text=True, timeout=600,
+                              env=dict(env, TRT_BENCH_FAIL_DIST="1") if fail else env, cwd=T.ROOT)
+    out = run([], True)
+    assert out.returncode != 0, out.stdout[-500:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
+    assert "TRT_BENCH_FAIL_DIST is set" in out.stderr and "no fallback was allowed" in out.stderr, out.stderr[-1500:]
+    # ... unless the PyTorch-level gather was explicitly allowed: then the line names the fallback and its reason
+    out = run(["--allow-fallback"], True)
+    assert out.returncode == 0, out.stderr[-1500:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["multi_gpu_path"].startswith("FALLBACK") and line["rccl_ranks"] is None, line["config"]
 
 
 def test_sharded_renderer_world_of_one(ctx):
