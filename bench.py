@@ -601,9 +601,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["text"] if args.sky_dim == SKY_DIM else wl["text"].replace("256^2", f"{args.sky_dim}^2"), "sharding": f"{world} x interleaved {args.tile_rows}-row tiles, 1 gather/frame",
                        "multi_gpu_path": "PyTorch-level rehearsal (gloo)" if rehearsal else
-                                         ("C-ABI trt_dist_* (send/recv gather inside the library) over a STAND-IN for RCCL: " + stand_in if stand_in and world > 1 else
-                                          "C-ABI trt_dist_* (RCCL send/recv gather inside the library)" if fallback_reason is None else
-                                          "FALLBACK: PyTorch-level gather (torch.distributed " + args.backend + "); trt_dist_* failed: " + fallback_reason),
+                                         ("FALLBACK (--allow-fallback): PyTorch-level gather (torch.distributed " + args.backend + "); trt_dist_* failed: " + fallback_reason
+                                          if fallback_reason is not None else
+                                          "C-ABI trt_dist_* (send/recv gather inside the library) over a STAND-IN for RCCL: " + stand_in if stand_in and world > 1 else
+                                          "C-ABI trt_dist_* (RCCL send/recv gather inside the library)"),
                        "kernel": {0: "persistent waves, synchronous rounds" + (", shading decoupled from the owning lane" if variant["decoupled"] else ""),
                                   1: "reference-order"}[args.kernel],
                        "workgroup_threads": variant["workgroup_threads"],

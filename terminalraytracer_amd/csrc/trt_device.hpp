@@ -82,12 +82,7 @@ TRT_DEV double sqrt_exact(double x) // == __builtin_sqrt(x)
 #ifndef TRT_LEAN_UNIT
 #define TRT_LEAN_UNIT 2
 #endif
-// `is_unit` (out): the result is KNOWN to be a unit vector to within 12u -- far inside the |d.d - 1| <= 2^-40 the candidate
-// tables ask of a ray (trt_lightgrid.h, trt_raygrid.h) -- because it was divided by its length and nothing left the normal range:
-// len = |a| (1 +- 2u) (the sum of squares of components that are zero or >= 2^-300 rounds three times, the root once),
-// every quotient is a_k / len (1 +- u), so sum q_k^2 = 1 +- 8u, and forming that sum adds 3u.  false says nothing (the caller
-// then tests d.d itself).  Saves the callers five FP64 operations and a compare per ray.
-TRT_DEV d3 unit(d3 a, bool &is_unit)
+TRT_DEV d3 unit(d3 a)
 {
     const double len = sqrt_exact(a.x * a.x + a.y * a.y + a.z * a.z);
 #if TRT_LEAN_MATH && TRT_LEAN_UNIT == 2
@@ -102,7 +97,6 @@ TRT_DEV d3 unit(d3 a, bool &is_unit)
     int lo = ex < ey ? ex : ey;
     lo = lo < ez ? lo : ez;
     const bool ok = len < 0x1p300 && lo > -300;
-    is_unit = longer && ok;
     if (TRT_LIKELY(!__any(!ok)))
     {
         const double den = longer ? len : 1.0;
@@ -131,7 +125,6 @@ TRT_DEV d3 unit(d3 a, bool &is_unit)
     }
     return a;
 #else
-    is_unit = false;
     if (len > 0.0001)
     {
 #if TRT_LEAN_MATH
@@ -167,12 +160,6 @@ TRT_DEV d3 unit(d3 a, bool &is_unit)
     }
     return a;
 #endif
-}
-
-TRT_DEV d3 unit(d3 a)
-{
-    bool ignored;
-    return unit(a, ignored);
 }
 
 // the compiler's own expansions, for trt_selftest_unit

@@ -42,9 +42,6 @@
 #ifndef TRT_OPT_DIRCONST
 #define TRT_OPT_DIRCONST 1
 #endif
-#ifndef TRT_OPT_UNITFLAG
-#define TRT_OPT_UNITFLAG 0 // unit()'s "known to be of length 1" instead of testing d.d: 1 path rays, 2 point-light shadow rays, 3 both, 4 branch-free (measured SLOWER)
-#endif
 #ifndef TRT_OPT_POOLCHECK
 #define TRT_OPT_POOLCHECK 1 // the exact loops ask the lanes for a pool word only in the iterations that can need one
 #endif
@@ -558,21 +555,7 @@ TRT_DEV void point_light_search(const LdsImage &L, int n, d3 o, d3 d, bool activ
 // expected in (0 eye, 1 mirror eye, 2 + i sphere i, 2 + n + i mirror sphere i, < 0 none).  `fallback` is set for an active lane
 // whose ray fails the family's membership test (its line must pass within r_chk of the apex, its origin not more than r_chk
 // behind it, within the table's range; a unit direction) or whose cell has no list: the caller then sweeps.
-// `d_unit`: d is known to be a unit vector (unit()'s flag); a lane without that knowledge makes its wave test d.d.
-template <int WHICH>
-TRT_DEV bool unit_direction(d3 d, bool active, bool d_unit)
-{
-    bool ok = d_unit;
-    if (!(TRT_OPT_UNITFLAG & WHICH) && TRT_OPT_UNITFLAG != 4)
-        return __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
-    if (TRT_OPT_UNITFLAG == 4)
-        return d_unit; // experiment only: no fall-back test at all (a ray whose direction unit() left alone makes its wave sweep)
-    if (__any(active && !d_unit))
-        ok = d_unit || __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
-    return ok;
-}
-
-TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n, int fam, d3 o, d3 d, bool active, bool &fallback, bool d_unit = false)
+TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n, int fam, d3 o, d3 d, bool active, bool &fallback)
 {
     const bool has = active && fam >= 0;
     const int f = has ? fam : 0;
@@ -593,7 +576,7 @@ TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n
     const d3 w = sub(o, apex);
     const d3 c = d3{w.y * d.z - w.z * d.y, w.z * d.x - w.x * d.z, w.x * d.y - w.y * d.x};
     const bool near_line = dot(c, c) <= r_chk * r_chk, ahead = dot(w, d) >= -r_chk, in_range = dot(w, w) <= rg2;
-    const bool unit_dir = unit_direction<1>(d, active, d_unit);
+    const bool unit_dir = __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
     const bool member = near_line & ahead & in_range & unit_dir;
     const int g = of_eye ? G.g_eye : G.g_sph;
     const int at = trt_cubemap_cell((float)d.x, (float)d.y, (float)d.z, 0.5f * (float)g, (float)(g - 1), g);
@@ -614,7 +597,7 @@ TRT_DEV unsigned long long path_cell(const LdsImage &L, const GridView &G, int n
 // from the ground cannot hit the ground again).  `fallback` is set for an active lane whose ray fails the family's
 // membership test (its line must pass within r_chk of the apex, its origin not more than r_chk behind it, within the table's
 // range; a unit direction) or whose cell has no list: the caller then sweeps.
-TRT_DEV unsigned long long path_cell_patches(const LdsImage &L, const GridView &G, int n, int &fam, d3 o, d3 d, bool active, bool &fallback, bool d_unit = false)
+TRT_DEV unsigned long long path_cell_patches(const LdsImage &L, const GridView &G, int n, int &fam, d3 o, d3 d, bool active, bool &fallback)
 {
     const bool has = active && fam >= 0;
     const int f = has ? fam : 0;
@@ -648,7 +631,7 @@ TRT_DEV unsigned long long path_cell_patches(const LdsImage &L, const GridView &
     const d3 w = sub(o, apex);
     const d3 c = d3{w.y * d.z - w.z * d.y, w.z * d.x - w.x * d.z, w.x * d.y - w.y * d.x};
     const bool near_line = dot(c, c) <= r_chk * r_chk, ahead = dot(w, d) >= -r_chk, in_range = dot(w, w) <= rg2;
-    const bool unit_dir = unit_direction<1>(d, active, d_unit);
+    const bool unit_dir = __builtin_fabs(dot(d, d) - 1.0) <= 9.094947017729282e-13;
     const bool member = near_line & ahead & in_range & unit_dir;
     const int g = of_eye ? G.g_eye : G.g_sph;
     const int at = trt_cubemap_cell((float)d.x, (float)d.y, (float)d.z, 0.5f * (float)g, (float)(g - 1), g);
@@ -705,7 +688,7 @@ struct PathHit
 // does, it has no family).
 template <bool COUNT, bool REFRACT = false, bool PATCHES = false>
 TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridView &grids, int n, d3 o, d3 d, int &fam, bool alive, d3 gp, d3 gn,
-                           Tally &tally, int inside = -1, bool d_unit = false)
+                           Tally &tally, int inside = -1)
 {
     TRT_STAGE_STAMPS(tally);
     bool p_list = false;
@@ -714,9 +697,9 @@ TRT_DEV PathHit path_stage(const LdsImage &L, const CullView &cull, const GridVi
     {
         bool fallback;
         if constexpr (PATCHES)
-            p_cell = path_cell_patches(L, grids, n, fam, o, d, alive, fallback, d_unit); // fam: now what a reflection by the ground belongs to
+            p_cell = path_cell_patches(L, grids, n, fam, o, d, alive, fallback); // fam: now what a reflection by the ground belongs to
         else
-            p_cell = path_cell(L, grids, n, fam, o, d, alive, fallback, d_unit);
+            p_cell = path_cell(L, grids, n, fam, o, d, alive, fallback);
         p_list = !__any(fallback);
     }
     if (COUNT && !p_list)
@@ -806,8 +789,7 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
             const d3 to_light = sub(load3(pl), o);
             const double light_d2 = dot(to_light, to_light);
             const double strength = clampd(pl[6] / light_d2, 0.0, 1.0);
-            bool sd_unit;
-            sd = unit(to_light, sd_unit);
+            sd = unit(to_light);
             lcolor = load3(pl + 3);
             bool use_list = false;
             unsigned long long cell = 0;
@@ -816,7 +798,7 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
                 const trt_pointgrid *G = L.pointgrid + (li - nd);
                 int far;
                 const int c = trt_pointgrid_cell(G, o.x, o.y, o.z, &far);
-                far |= !unit_direction<2>(sd, lit_lanes, sd_unit);
+                far |= !(__builtin_fabs(dot(sd, sd) - 1.0) <= 9.094947017729282e-13);
                 if (lit_lanes && !far)
                     cell = grids.point_lists[(size_t)(li - nd) * grids.point_stride + (unsigned)c];
                 use_list = !__any(lit_lanes && (far || (unsigned)(cell >> 56) == TRT_LIST_NONE));
@@ -1119,8 +1101,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         if (COUNT)
             tally.rounds++;
         TRT_STAMP_AT(0); // units + primary rays
-        bool d_unit;
-        d = unit(next_dir, d_unit); // TRT.c:1008 for a primary ray, TRT.c:1055 for a reflected one; d_unit: known to be of length 1
+        d = unit(next_dir); // TRT.c:1008 for a primary ray, TRT.c:1055 for a reflected one
 
         // ======================================= P: the path ray =======================================
         if (COUNT && alive)
@@ -1129,7 +1110,7 @@ __global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPAC
         PathHit hit;
         {
             TRT_FRESH_ARGS;
-            hit = path_stage<COUNT, REFRACT, PATCHES>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside, d_unit);
+            hit = path_stage<COUNT, REFRACT, PATCHES>(L, cull, grids, n, o, d, fam, alive, gp, gn, tally, inside);
         }
         if constexpr (COMPACT)
         {
