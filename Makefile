@@ -27,14 +27,14 @@ $(BUILD)/host_%.o: $(CSRC)/host/%.c include/trt.h include/trt_host.h
 	@mkdir -p $(BUILD)
 	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
-$(BUILD)/trt_capi$(TAG).o: $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h
+$(BUILD)/trt_capi$(TAG).o: $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h include/trt_hip_diag.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o $@ $(CSRC)/trt_capi.hip 2> $(BUILD)/resource_usage$(TAG).txt \
 		|| (cat $(BUILD)/resource_usage$(TAG).txt; false)
 	@grep -E "error|warning:" $(BUILD)/resource_usage$(TAG).txt || true
 	@awk '/Function Name: .*render_rounds_kernelILb0/ {f=1} f && /VGPRs:/ {split($$0,a,"VGPRs: "); v=a[2]+0; print "render_rounds_kernel<false>: " v " VGPRs" (v>128 ? "  ** WARNING: more than 128 -> 3 waves/SIMD **" : " (4 waves/SIMD)"); exit}' $(BUILD)/resource_usage$(TAG).txt
 
-$(BUILD)/trt_dist.o: $(CSRC)/trt_dist.hip include/trt.h include/trt_hip.h
+$(BUILD)/trt_dist.o: $(CSRC)/trt_dist.hip include/trt.h include/trt_hip.h include/trt_hip_diag.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/trt_dist.hip
 

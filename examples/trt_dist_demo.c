@@ -20,6 +20,7 @@
 #include <unistd.h>
 
 #include "trt_hip.h"
+#include "trt_hip_diag.h"
 #include "trt_host.h"
 
 static double now_seconds(void)

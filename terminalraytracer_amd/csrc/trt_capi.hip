@@ -1,6 +1,7 @@
 // trt_capi.hip -- host side of libtrt_hip.so: contexts, uploads, launches.  C-ABI of include/trt_hip.h.
 // Compiled for gfx950 only, with -ffp-contract=off (see trt_device.hpp).
 #include "trt_hip.h"
+#include "trt_hip_diag.h"
 
 #include <hip/hip_runtime.h>
 
@@ -438,7 +439,7 @@ __global__ void pack_lists_kernel(const unsigned long long *masks, long cells, i
 // camera for the eye's two tables at 256 spheres: 192 blocks of long dependent FP64 chains.  Tiles of 16 x 16: 0.16 ms.)
 // Otherwise: one thread per cell, 256 consecutive cells per block, every sphere.  `by_value`: the two families of the eye come
 // as kernel arguments (they change with the camera), otherwise family blockIdx.y of `families`.
-static_assert(TRT_FAMILY_TILE * TRT_FAMILY_TILE == 64 && TRT_LIST_MAX_SPHERES <= 256, "a tile per wave, a sphere per thread");
+static_assert(TRT_FAMILY_TILE * TRT_FAMILY_TILE == 64, "a tile per wave");
 constexpr int kSceneTilesPerBlock = 16; // the scene's sphere families: thousands of tables, 16 tiles from one set of cones
 unsigned family_grid_blocks(int g, int tiles_per_block)
 {
@@ -446,15 +447,26 @@ unsigned family_grid_blocks(int g, int tiles_per_block)
     return trt_family_tiled(g) ? (cells / 64u + (unsigned)tiles_per_block - 1u) / (unsigned)tiles_per_block : (cells + 255u) / 256u;
 }
 
+// kWords: 64-sphere mask words a cell can have -- 4 for scenes of up to 256 spheres (8-bit list entries), 16 for scenes of up to
+// TRT_PATH_MAX_SPHERES = 1024 (16-bit entries; round 5: before, the path rays of a scene of more than 256 spheres swept).  The LDS
+// is the launch's dynamic allocation (family_lds_bytes): the family's cones, the tile's reach words, the four waves' marks.
+template <int kWords>
+constexpr size_t family_lds_bytes()
+{
+    return sizeof(trt_pointgrid_cone) * 64 * kWords + sizeof(unsigned long long) * kWords + sizeof(unsigned long long) * 4 * 64 * kWords;
+}
+
+template <int kWords>
 __global__ __launch_bounds__(256) void build_family_lists_kernel(const double *spheres, int n, const trt_rayfamily *families, trt_rayfamily f0,
                                                                  trt_rayfamily f1, int by_value, int g, unsigned long long *lists,
                                                                  unsigned long long *pool, unsigned long long *pool_used, unsigned pool_limit,
                                                                  int tiles_per_block)
 {
-    constexpr int kWords = TRT_LIST_MAX_SPHERES / 64;
-    __shared__ trt_pointgrid_cone cones[TRT_LIST_MAX_SPHERES];
-    __shared__ unsigned long long reach[kWords];          // bit k of word w: sphere 64 w + k reaches this block's tile
-    __shared__ unsigned long long part[4][64][kWords];    // wave q's marks of the tile's cells
+    extern __shared__ __attribute__((aligned(16))) unsigned char family_lds[];
+    trt_pointgrid_cone *const cones = (trt_pointgrid_cone *)family_lds;                  // [64 kWords]
+    unsigned long long *const reach = (unsigned long long *)(cones + 64 * kWords);       // [kWords]: bit k of word w: sphere 64 w + k reaches this block's tile
+    unsigned long long(*const part)[64][kWords] = (unsigned long long(*)[64][kWords])(reach + kWords); // [4]: wave q's marks of the tile's cells
+    const int bits = kWords > 4 ? 16 : 8; // entry width of the list cells (trt_raygrid.h)
     const trt_rayfamily F = by_value ? (blockIdx.y == 0 ? f0 : f1) : families[blockIdx.y];
     for (int i = threadIdx.x; i < n; i += blockDim.x)
         trt_rayfamily_cone(&F, spheres + 9 * i, &cones[i]);
@@ -466,11 +478,14 @@ __global__ __launch_bounds__(256) void build_family_lists_kernel(const double *s
         const unsigned cell = blockIdx.x * blockDim.x + threadIdx.x;
         const bool valid = cell < cells;
         const int face = (int)(cell / ((unsigned)g * (unsigned)g)), j = (int)((cell / (unsigned)g) % (unsigned)g), c = (int)(cell % (unsigned)g);
-        unsigned long long m[kWords] = {0, 0, 0, 0};
+        unsigned long long m[kWords];
+#pragma unroll
+        for (int w = 0; w < kWords; w++)
+            m[w] = 0;
         for (int i = 0; valid && i < n; i++)
             if (trt_pointgrid_reaches(&cones[i], face, c, j, g))
                 m[i >> 6] |= 0x8000000000000000ull >> (i & 63);
-        const unsigned long long packed = pack_cell(m, words, pool, pool_used, pool_limit, 8, valid);
+        const unsigned long long packed = pack_cell(m, words, pool, pool_used, pool_limit, bits, valid);
         if (valid)
             lists[(size_t)blockIdx.y * cells + cell] = packed;
         return;
@@ -482,11 +497,16 @@ __global__ __launch_bounds__(256) void build_family_lists_kernel(const double *s
     for (unsigned tile = blockIdx.x * (unsigned)tiles_per_block; tile < tiles && tile < (blockIdx.x + 1u) * (unsigned)tiles_per_block; tile++)
     {
         const int face = (int)(tile / (gt * gt)), tj = (int)((tile / gt) % gt), tc = (int)(tile % gt);
-        const bool reaches = (int)threadIdx.x < n && trt_pointgrid_reaches(&cones[threadIdx.x], face, tc, tj, (int)gt);
-        const unsigned long long word = __ballot(reaches); // the 64 spheres of this wave
         __syncthreads(); // the previous tile's reach[] and part[] have been read
-        if (lane == 0)
-            reach[q] = word;
+#pragma unroll
+        for (int chunk = 0; chunk < kWords / 4; chunk++) // thread t asks for spheres t, 256 + t, ...: wave q's ballot is word 4 chunk + q
+        {
+            const int i = 256 * chunk + (int)threadIdx.x;
+            const bool reaches = i < n && trt_pointgrid_reaches(&cones[i], face, tc, tj, (int)gt);
+            const unsigned long long word = __ballot(reaches); // the 64 spheres of this wave
+            if (lane == 0)
+                reach[4 * chunk + q] = word;
+        }
         __syncthreads();
         const int j = tj * TRT_FAMILY_TILE + lane / TRT_FAMILY_TILE, c = tc * TRT_FAMILY_TILE + lane % TRT_FAMILY_TILE;
 #pragma unroll
@@ -511,9 +531,22 @@ __global__ __launch_bounds__(256) void build_family_lists_kernel(const double *s
             for (int w = 0; w < kWords; w++)
                 m[w] = part[0][lane][w] | part[1][lane][w] | part[2][lane][w] | part[3][lane][w];
             const unsigned cell = ((unsigned)face * (unsigned)g + (unsigned)j) * (unsigned)g + (unsigned)c;
-            lists[(size_t)blockIdx.y * cells + cell] = pack_cell(m, words, pool, pool_used, pool_limit, 8);
+            lists[(size_t)blockIdx.y * cells + cell] = pack_cell(m, words, pool, pool_used, pool_limit, bits);
         }
     }
+}
+
+// the builder for a scene of n spheres: 4 mask words (8-bit entries) up to 256 spheres, 16 (16-bit entries) up to 1024
+void launch_family_builder(int n, dim3 grid, hipStream_t stream, const double *spheres, const trt_rayfamily *families, trt_rayfamily f0, trt_rayfamily f1,
+                           int by_value, int g, unsigned long long *lists, unsigned long long *pool, unsigned long long *pool_used, unsigned pool_limit,
+                           int tiles_per_block)
+{
+    if (n <= TRT_LIST_MAX_SPHERES)
+        hipLaunchKernelGGL(build_family_lists_kernel<4>, grid, dim3(256), family_lds_bytes<4>(), stream, spheres, n, families, f0, f1, by_value, g, lists, pool,
+                           pool_used, pool_limit, tiles_per_block);
+    else
+        hipLaunchKernelGGL(build_family_lists_kernel<TRT_PATH_MAX_SPHERES / 64>, grid, dim3(256), family_lds_bytes<TRT_PATH_MAX_SPHERES / 64>(), stream, spheres, n,
+                           families, f0, f1, by_value, g, lists, pool, pool_used, pool_limit, tiles_per_block);
 }
 
 // Light-space candidate masks of every light (trt_lightgrid.h), from the context's host copy of the primitives: the
@@ -630,7 +663,7 @@ int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const double *
     ctx->T->cull_scene = cs;
     memcpy(ctx->T->ground_built, ground, sizeof ctx->T->ground_built);
     const int ge = ctx->path_g_eye, gs = ctx->path_g_sph;
-    if (ge < 2 || gs < 2 || n > TRT_LIST_MAX_SPHERES || n < ctx->path_min_spheres)
+    if (ge < 2 || gs < 2 || n > TRT_PATH_MAX_SPHERES || n < ctx->path_min_spheres)
         return TRT_OK; // path_enabled = 0: every path ray sweeps
     trt_patchset patches;
     trt_patchset_init(&patches, patches_for(ctx, n));
@@ -656,10 +689,10 @@ int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const double *
         for (size_t first = 0; first < families; first += 32768) // grid.y is limited to 65535
         {
             const unsigned batch = (unsigned)std::min<size_t>(32768, families - first);
-            hipLaunchKernelGGL(build_family_lists_kernel, dim3(family_grid_blocks(gs, kSceneTilesPerBlock), batch), dim3(256), 0, ctx->stream,
-                               (const double *)ctx->T->d_spheres.ptr, n, (const trt_rayfamily *)ctx->T->d_families.ptr + first, trt_rayfamily{}, trt_rayfamily{}, 0,
-                               gs, ctx->T->d_path_lists.ptr + eye_part + first * sph_cells, ctx->T->d_pool.ptr, ctx->T->d_pool_used.ptr, (unsigned)ctx->T->pool_scene_words,
-                               kSceneTilesPerBlock);
+            launch_family_builder(n, dim3(family_grid_blocks(gs, kSceneTilesPerBlock), batch), ctx->stream, (const double *)ctx->T->d_spheres.ptr,
+                                  (const trt_rayfamily *)ctx->T->d_families.ptr + first, trt_rayfamily{}, trt_rayfamily{}, 0, gs,
+                                  ctx->T->d_path_lists.ptr + eye_part + first * sph_cells, ctx->T->d_pool.ptr, ctx->T->d_pool_used.ptr, (unsigned)ctx->T->pool_scene_words,
+                                  kSceneTilesPerBlock);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -691,23 +724,41 @@ int build_tables(trt_context *ctx, const trt_cull_scene &cs, const double *groun
     // half a word per cell -- a list that finds no room leaves its cell TRT_LIST_NONE and its rays sweep
     const int m = patches_for(ctx, (int)n);
     const size_t sphere_cells = 2 * n * (m ? 6 * (size_t)m * m : 1) * 6 * gs * gs;
-    ctx->T->pool_scene_words = std::max<size_t>(1024, nd * sd * gd * gd + np * 6 * sp * gp * gp + (m ? sphere_cells / 2 : sphere_cells));
-    ctx->T->pool_eye_words = std::max<size_t>(1024, 2 * 6 * ge * ge);
-    if (ctx->T->pool_scene_words + kEyeSlots * ctx->T->pool_eye_words >= 0xffffffffull)
-        return fail(TRT_ERR_CAPACITY, "candidate tables too large");
-    if (n > TRT_LIST_MAX_SPHERES) // no sphere families; 16-bit entries: long lists take twice the words
-        ctx->T->pool_scene_words = std::max<size_t>(1024, 2 * (nd * sd * gd * gd + np * 6 * sp * gp * gp));
+    // (scenes of more than 256 spheres: 16-bit entries, a long list takes twice the words; beyond TRT_PATH_MAX_SPHERES no sphere families)
+    const size_t wide = n > TRT_LIST_MAX_SPHERES ? 2 : 1, sphere_part = n > TRT_PATH_MAX_SPHERES ? 0 : (m ? sphere_cells / 2 : sphere_cells);
+    ctx->T->pool_scene_words = std::max<size_t>(1024, wide * (nd * sd * gd * gd + np * 6 * sp * gp * gp + sphere_part));
+    // The eye's two tables are rebuilt for every camera, on the frame's stream: nobody can look at their counter and grow their part
+    // afterwards, so it holds the longest lists there can be -- every sphere in every cell, up to 64 words (512 / 256 entries) a cell.
+    // (Round 4 gave them one word per cell: enough at 64 and 256 spheres, not in a scene of 700, whose primary rays then swept.)
+    const size_t per_word = wide == 2 ? 4 : 8;
+    ctx->T->pool_eye_words = std::max<size_t>(1024, 2 * 6 * ge * ge * std::min<size_t>((n + per_word - 1) / per_word, 64));
     if (ctx->list_pool_cap) // trt_set_list_pool_words (tests: the pool's exhaustion)
         ctx->T->pool_scene_words = std::min(ctx->T->pool_scene_words, std::max<size_t>(ctx->list_pool_cap, 1));
-    ctx->grids = trt::GridView{};
-    ctx->grids.list_bits = 8;
-    HIP_TRY(ctx->T->d_pool.reserve(ctx->T->pool_scene_words + kEyeSlots * ctx->T->pool_eye_words));
-    HIP_TRY(ctx->T->d_pool_used.reserve(16 * (1 + kEyeSlots)));
-    HIP_TRY(hipMemsetAsync(ctx->T->d_pool_used.ptr, 0, 16 * (1 + kEyeSlots) * sizeof(unsigned long long), ctx->stream));
     const double t0 = host_seconds();
-    int rc = build_light_grids(ctx, cs);
-    if (!rc)
-        rc = build_path_tables(ctx, cs, ground);
+    int rc = TRT_OK;
+    // The scene's part is sized by a guess (a word per cell) and GROWN to what the builders asked for if that was more: the
+    // counter keeps counting after the part is exhausted (pack_cell), so one more pass with a part of that size has room for
+    // every list.  Dense scenes of many spheres need it (700 spheres: ~7 words a cell); the BASELINE configs never do.
+    for (int pass = 0; pass < 2 && !rc; pass++)
+    {
+        if (ctx->T->pool_scene_words + kEyeSlots * ctx->T->pool_eye_words >= 0xffffffffull)
+            return fail(TRT_ERR_CAPACITY, "candidate tables too large");
+        ctx->grids = trt::GridView{};
+        ctx->grids.list_bits = n > TRT_LIST_MAX_SPHERES ? 16 : 8; // every table of the scene: the light tables' and the families' lists alike
+        HIP_TRY(ctx->T->d_pool.reserve(ctx->T->pool_scene_words + kEyeSlots * ctx->T->pool_eye_words));
+        HIP_TRY(ctx->T->d_pool_used.reserve(16 * (1 + kEyeSlots)));
+        HIP_TRY(hipMemsetAsync(ctx->T->d_pool_used.ptr, 0, 16 * (1 + kEyeSlots) * sizeof(unsigned long long), ctx->stream));
+        rc = build_light_grids(ctx, cs);
+        if (!rc)
+            rc = build_path_tables(ctx, cs, ground);
+        if (rc || ctx->list_pool_cap)
+            break; // a capped pool (tests) stays capped
+        unsigned long long asked = 0;
+        HIP_TRY(hipMemcpy(&asked, ctx->T->d_pool_used.ptr, sizeof asked, hipMemcpyDeviceToHost)); // the builders have been synchronised
+        if (asked <= ctx->T->pool_scene_words)
+            break;
+        ctx->T->pool_scene_words = (size_t)asked + 1024;
+    }
     ctx->T->build_seconds = host_seconds() - t0;
     return rc;
 }
@@ -728,9 +779,8 @@ int ensure_eye_tables(trt_context *ctx, const Camera *camera, hipStream_t stream
     const size_t pool_from = ctx->T->pool_scene_words + (size_t)ctx->eye_slot * ctx->T->pool_eye_words;
     unsigned long long *const counter = ctx->T->d_pool_used.ptr + 16 * (1 + ctx->eye_slot);
     hipLaunchKernelGGL(set_pool_counter_kernel, dim3(1), dim3(1), 0, stream, counter, (unsigned long long)pool_from);
-    hipLaunchKernelGGL(build_family_lists_kernel, dim3(family_grid_blocks(ge, 1), 2u), dim3(256), 0, stream, (const double *)ctx->T->d_spheres.ptr, n,
-                       (const trt_rayfamily *)nullptr, g.eye[0], g.eye[1], 1, ge, ctx->T->d_path_lists.ptr + g.eye_at, ctx->T->d_pool.ptr, counter,
-                       (unsigned)(pool_from + ctx->T->pool_eye_words), 1);
+    launch_family_builder(n, dim3(family_grid_blocks(ge, 1), 2u), stream, (const double *)ctx->T->d_spheres.ptr, (const trt_rayfamily *)nullptr, g.eye[0], g.eye[1], 1,
+                          ge, ctx->T->d_path_lists.ptr + g.eye_at, ctx->T->d_pool.ptr, counter, (unsigned)(pool_from + ctx->T->pool_eye_words), 1);
     HIP_TRY(hipGetLastError());
     memcpy(ctx->eye_built, eye, sizeof eye);
     ctx->eye_tables_valid = true;
@@ -993,6 +1043,7 @@ static int init_context(trt_context *ctx)
     HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int)));
     // dynamic LDS above the 64 KiB default needs the opt-in attribute
+    (void)hipFuncSetAttribute((const void *)build_family_lists_kernel<TRT_PATH_MAX_SPHERES / 64>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::probe_rays_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);

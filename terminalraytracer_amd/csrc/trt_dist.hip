@@ -14,6 +14,7 @@
 // RCCL is bound at run time (dlopen of librccl.so.1; a process that already carries one -- PyTorch bundles its own -- keeps
 // using that one), so libtrt_hip.so itself does not depend on it and single-GPU hosts never load it.
 #include "trt_hip.h"
+#include "trt_hip_diag.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>

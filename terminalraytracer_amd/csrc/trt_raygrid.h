@@ -40,7 +40,7 @@
  * cell: byte 7 = count 0..7 and bytes 0..6 the sphere indices in ascending order; or byte 7 = 0x80, bits 32..47 = count,
  * bits 0..31 = the offset of ceil(count/8) words of indices in a pool; or byte 7 = 0xFF: no list (pool exhausted), the
  * ray falls back to the sweep.  One 8-byte load whatever N is, and the exact stage pops bytes.  Scenes of more than 256
- * spheres use 16-bit entries (3 inline, 4 per pool word) for their light tables and sweep for their path rays.
+ * spheres use 16-bit entries (3 inline, 4 per pool word) in every table; beyond 1024 spheres their path rays sweep.
  */
 #ifndef TRT_RAYGRID_H
 #define TRT_RAYGRID_H
@@ -57,9 +57,11 @@ typedef struct
 
 #define TRT_RAYFAMILY_DOUBLES 6
 
-/* list cells index spheres with 8 bits (scenes of up to 256 spheres: every table) or 16 bits (light tables of larger scenes;
- * the path rays' family tables are only built up to TRT_LIST_MAX_SPHERES) */
+/* list cells index spheres with 8 bits (scenes of up to 256 spheres: every table) or 16 bits (larger scenes: the light tables up to
+ * TRT_LIST_MAX_SPHERES_WIDE spheres, the path rays' family tables up to TRT_PATH_MAX_SPHERES -- a workgroup of the device builder
+ * holds a family's cones, 64 bytes a sphere, and its tile's mask words in LDS; beyond that the path rays sweep) */
 #define TRT_LIST_MAX_SPHERES 256
+#define TRT_PATH_MAX_SPHERES 1024
 #define TRT_LIST_MAX_SPHERES_WIDE 65535
 #define TRT_LIST_POOLED 0x80u
 #define TRT_LIST_NONE 0xFFu

@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include "trt_hip.h"
+#include "trt_hip_diag.h"
 #include "trt_host.h"
 
 typedef struct

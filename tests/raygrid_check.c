@@ -76,6 +76,7 @@ typedef struct
     unsigned long long *cells; /* list cells: 2 * 6 g_eye^2, then 2 n P * 6 g_sph^2 */
     unsigned long long *pool;
     size_t pool_words, pool_cap;
+    int bits; /* entry width of the list cells: 8 up to 256 spheres, 16 above (trt_raygrid.h) */
 } tables;
 
 static size_t family_base(const tables *T, int f)
@@ -129,7 +130,8 @@ static tables *build(const double *spheres, int n, const double *ground, const d
     const int words = (n + 63) / 64 > 0 ? (n + 63) / 64 : 1;
     const size_t total = family_base(T, T->families);
     T->cells = (unsigned long long *)malloc(sizeof(unsigned long long) * total);
-    T->pool_cap = total;
+    T->bits = n > TRT_LIST_MAX_SPHERES ? 16 : 8;
+    T->pool_cap = total * (size_t)(T->bits / 8);
     T->pool = (unsigned long long *)malloc(sizeof(unsigned long long) * T->pool_cap);
     unsigned long long bits = 0;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : bits)
@@ -146,17 +148,17 @@ static tables *build(const double *spheres, int n, const double *ground, const d
             const int count = trt_list_count(masks + c * words, words);
             size_t at = 0;
             int room = 1;
-            if (count > 7)
+            if (trt_list_pool_words(count, T->bits))
             {
 #pragma omp critical
                 {
                     at = T->pool_words;
-                    room = at + (size_t)trt_list_pool_words(count, 8) <= T->pool_cap;
+                    room = at + (size_t)trt_list_pool_words(count, T->bits) <= T->pool_cap;
                     if (room)
-                        T->pool_words += (size_t)trt_list_pool_words(count, 8);
+                        T->pool_words += (size_t)trt_list_pool_words(count, T->bits);
                 }
             }
-            out[c] = trt_list_pack(masks + c * words, words, count, room ? T->pool : NULL, (unsigned)at, 8);
+            out[c] = trt_list_pack(masks + c * words, words, count, room ? T->pool : NULL, (unsigned)at, T->bits);
         }
         free(cones);
         free(masks);
@@ -187,7 +189,7 @@ static int in_list(const tables *T, unsigned long long cell, int sphere)
     int prev = -1;
     for (int k = 0; k < e; k++)
     {
-        const int i = trt_list_entry(cell, T->pool, k, 8);
+        const int i = trt_list_entry(cell, T->pool, k, T->bits);
         if (i <= prev)
             return -2; /* not ascending: a malformed list */
         prev = i;

@@ -11,20 +11,26 @@ import support as T
 from terminalraytracer_amd import hip
 
 
-def _declared_symbols():
-    text = open(os.path.join(T.ROOT, "include", "trt_hip.h")).read()
+def _declared_symbols(header="trt_hip.h"):
+    text = open(os.path.join(T.ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b(project_scene|render_frame|trt_[a-z0-9_]+)\s*\(", text)
     return sorted(set(names))
 
 
 def test_library_exports_every_declared_symbol():
+    """include/trt_hip.h is the product boundary, include/trt_hip_diag.h the bench-top (counters, read-backs, self-tests, probes,
+    test hooks): the library exports every symbol either declares, the binding knows exactly those, and nothing of the
+    bench-top has crept back into the product header."""
     dll = hip.lib()
-    declared = _declared_symbols()
-    assert "project_scene" in declared and "render_frame" in declared and len(declared) >= 20
-    for name in declared:
-        assert hasattr(dll, name), f"{name} declared in include/trt_hip.h but not exported"
-    assert set(declared) == set(hip.SYMBOLS), set(declared) ^ set(hip.SYMBOLS)
+    product, diag = _declared_symbols(), _declared_symbols("trt_hip_diag.h")
+    assert "project_scene" in product and "render_frame" in product and len(product) >= 20
+    assert not set(product) & set(diag)
+    assert not [n for n in product if re.search(r"selftest|probe|read_(path_tables|light_grid|counters|diagnostics|loop|sweep|shading)|allow_rccl|pool_words", n)], product
+    for header, declared in (("trt_hip.h", product), ("trt_hip_diag.h", diag)):
+        for name in declared:
+            assert hasattr(dll, name), f"{name} declared in include/{header} but not exported"
+    assert set(product) | set(diag) == set(hip.SYMBOLS), (set(product) | set(diag)) ^ set(hip.SYMBOLS)
 
 
 def test_library_exports_every_host_side_symbol():

@@ -794,18 +794,20 @@ def test_light_space_tables_never_change_a_frame(ctx, cells):
         ctx.set_light_grids(128, 64)
 
 
-def _decode_cells(cells, pool):
-    """list cells (csrc/trt_raygrid.h) -> list of tuples of sphere indices; None for a cell without a list"""
+def _decode_cells(cells, pool, bits=8):
+    """list cells (csrc/trt_raygrid.h) -> list of tuples of sphere indices; None for a cell without a list.  bits: 8 per entry
+    up to 256 spheres (7 inline, 8 per pool word), 16 above (3 inline, 4 per pool word)"""
     out = []
+    per, mask = 64 // bits, (1 << bits) - 1
     for c in cells.tolist():
         ctl = c >> 56
         if ctl == 0xFF:
             out.append(None)
         elif ctl & 0x80:
             count, at = (c >> 32) & 0xFFFF, c & 0xFFFFFFFF
-            out.append(tuple((int(pool[at + (k >> 3)]) >> (8 * (k & 7))) & 0xFF for k in range(count)))
+            out.append(tuple((int(pool[at + k // per]) >> (bits * (k % per))) & mask for k in range(count)))
         else:
-            out.append(tuple((c >> (8 * k)) & 0xFF for k in range(ctl)))
+            out.append(tuple((c >> (bits * k)) & mask for k in range(ctl)))
     return out
 
 
@@ -845,25 +847,34 @@ def test_path_ray_tables_never_change_a_frame(ctx, cells):
         ctx.set_path_grids(64, 32)
 
 
-@pytest.mark.parametrize("n", [257, 300, 700])
-def test_scenes_of_more_than_256_spheres_keep_their_light_tables(ctx, n):
-    """List cells index spheres with one byte up to 256 spheres; larger scenes use 16-bit entries for the light tables and sweep
-    for their path rays (no family tables).  Frames and trace counts against the oracle, tables on / coarse / off."""
+@pytest.mark.parametrize("n", [257, 300, 700, 1030])
+def test_scenes_of_more_than_256_spheres_keep_their_tables(ctx, n):
+    """List cells index spheres with one byte up to 256 spheres; larger scenes use 16-bit entries -- for the light tables (up to
+    65535 spheres) and, since round 5, for the path rays' family tables too (up to 1024 spheres; beyond that the path rays
+    sweep).  Frames and trace counts against the oracle: every table on, one family per sphere / 6 patches, coarse tables, tables off."""
     scene = S.synth_scene(n, T.sky("synth"), T.bench_camera(72, 40, 2.5), seed=11)
     want, st = T.oracle_render(scene, 72, 40, 6, 4)
     ctx.enable_counters(True)
     try:
-        for cells in ((128, 64), (9, 3), (0, 0)):
-            ctx.set_light_grids(*cells)
+        for light_cells, path_cells, m in (((128, 64), (64, 32), 0), ((128, 64), (64, 16), 1), ((9, 3), (7, 3), 0), ((0, 0), (0, 0), 0)):
+            ctx.set_light_grids(*light_cells)
+            ctx.set_path_patches(m)
+            ctx.set_path_grids(*path_cells)
             got = render(ctx, scene, 72, 40, 6, 4)
-            assert np.array_equal(bits(got), bits(want)), (n, cells)
+            assert np.array_equal(bits(got), bits(want)), (n, light_cells, path_cells, m)
             assert ctx.read_counters() == (st.path_rays, st.shadow_rays)
             diag = ctx.read_diagnostics()
-            if cells == (128, 64):  # the shadow traces read lists: fewer swept traces than path + shadow stages together
-                assert diag["swept_traces"] < 2 * diag["wave_loop_trips"], diag
+            info = ctx.read_path_tables(scene.camera)[0]
+            assert info["enabled"] == (1 if path_cells[0] and n <= 1024 else 0), info
+            if light_cells == (128, 64) and n <= 1024:  # every trace reads a list: only rays beyond a table's range make their wave sweep
+                assert diag["swept_traces"] < 0.05 * 3 * diag["wave_loop_trips"], (n, path_cells, m, diag)
+            elif light_cells == (128, 64):  # beyond 1024 spheres the path rays sweep, the shadow rays read lists
+                assert diag["wave_loop_trips"] <= diag["swept_traces"] < 2 * diag["wave_loop_trips"], diag
     finally:
         ctx.enable_counters(False)
         ctx.set_light_grids(128, 64)
+        ctx.set_path_patches(-1)
+        ctx.set_path_grids(64, 32)
 
 
 def _degenerate_scenes():
@@ -979,10 +990,12 @@ def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
     g = base.ground.copy()
     g[0:6] = [0.3, -1.25, 0.2, 0.1, 2.0, -0.2]
     scenes = [S.synth_scene(64, T.sky("synth"), T.bench_camera(32, 18)), S.synth_scene(256, T.sky("synth"), T.bench_camera(32, 18, 2.5)),
-              S.SceneData(base.spheres, g, base.dir_lights, base.point_lights, base.camera, base.sky), R._odd_scenes()[4][1]]
+              S.SceneData(base.spheres, g, base.dir_lights, base.point_lights, base.camera, base.sky), R._odd_scenes()[4][1],
+              S.synth_scene(300, T.sky("synth"), T.bench_camera(32, 18, 2.5), seed=11)]  # 16-bit entries, the wide builder
     try:
         for scene in scenes:
-            for ge, gs, m in ((64, 32, 0), (11, 3, 0), (64, 8, 2), (16, 6, 1)):
+            wide = len(scene.spheres) > 256
+            for ge, gs, m in ((64, 16, 0), (11, 3, 0), (16, 8, 1)) if wide else ((64, 32, 0), (11, 3, 0), (64, 8, 2), (16, 6, 1)):
                 ctx.set_path_patches(m)
                 ctx.set_path_grids(ge, gs)
                 ctx.set_scene(scene)
@@ -995,11 +1008,12 @@ def test_device_built_path_tables_equal_the_host_reference_builder(ctx):
                 ground = np.ascontiguousarray(scene.ground, dtype=np.float64)
                 eye = np.ascontiguousarray(scene.camera[9:12], dtype=np.float64)
                 want_cells = np.zeros(len(cells), dtype=np.uint64)
-                want_pool = np.zeros(len(cells) + 16, dtype=np.uint64)
+                want_pool = np.zeros((2 if wide else 1) * len(cells) + 16, dtype=np.uint64)
                 used = lib.raygrid_host_cells(sph.ctypes.data, n, ground.ctypes.data, eye.ctypes.data, ge, gs, m, want_cells.ctypes.data,
                                               want_pool.ctypes.data, len(want_pool))
                 assert 0 <= used <= len(want_pool)
-                got, want = _decode_cells(cells, pool), _decode_cells(want_cells, want_pool)
+                got, want = _decode_cells(cells, pool, 16 if wide else 8), _decode_cells(want_cells, want_pool, 16 if wide else 8)
+                assert all(e is None or (list(e) == sorted(set(e)) and all(0 <= i < n for i in e)) for e in got)  # ascending sphere indices
                 # a pool too small for the long lists of a very coarse table leaves some cells without a list (their rays
                 # sweep); WHICH cells depends on the order the cells reserved their words in: compare the others
                 bad = [i for i, (a, b) in enumerate(zip(got, want)) if a != b and a is not None and b is not None]

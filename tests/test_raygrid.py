@@ -71,7 +71,9 @@ def describe(st):
 FRAMES = [("north-star scene, 64 spheres", lambda: S.synth_scene(64, T.sky("synth"), T.bench_camera(240, 135)), 240, 135, 8),
           ("demo scene", lambda: S.demo_scene(T.sky("synth"), T.bench_camera(160, 90)), 160, 90, 10),
           ("256 spheres", lambda: S.synth_scene(256, T.sky("synth"), T.bench_camera(96, 54)), 96, 54, 12),
-          ("mirror-heavy", lambda: S.synth_scene(64, T.sky("synth"), T.bench_camera(96, 54, 10.0), mirror_fraction=0.5), 96, 54, 8)]
+          ("mirror-heavy", lambda: S.synth_scene(64, T.sky("synth"), T.bench_camera(96, 54, 10.0), mirror_fraction=0.5), 96, 54, 8),
+          # more than 256 spheres: 16-bit list entries (3 inline, 4 per pool word; round 5: such scenes swept their path rays before)
+          ("300 spheres", lambda: S.synth_scene(300, T.sky("synth"), T.bench_camera(64, 36), seed=11), 64, 36, 8)]
 
 
 @pytest.mark.parametrize("name,make,w,h,b", FRAMES, ids=[f[0] for f in FRAMES])
@@ -82,7 +84,8 @@ def test_path_tables_hold_every_exact_hit_on_real_frames(checker, name, make, w,
     # coarse one, and the spheres' surfaces cut into 24 patches with a family each (coarser cells: the host build is slow) and into 6
     dense = len(scene.spheres) > 64
     whole = None
-    for g_eye, g_sph, m in ((64, 16 if dense else 32, 0), (7, 3, 0), (64, 8 if dense else 16, 2), (9, 4, 1)):
+    wide = len(scene.spheres) > 256  # the host build of 24 patches x 600 families would take minutes: one family per sphere and 6 patches
+    for g_eye, g_sph, m in ((64, 16, 0), (7, 3, 0), (64, 8, 1)) if wide else ((64, 16 if dense else 32, 0), (7, 3, 0), (64, 8 if dense else 16, 2), (9, 4, 1)):
         st = run(checker, scene, rays, kinds, g_eye, g_sph, patch_m=m)
         print(f"\n{name} g {g_eye}/{g_sph} patches m {m}: {describe(st)}")
         assert st.rays == int((kinds == 0).sum()) and st.violations == 0, list(st.first_violation)
@@ -91,7 +94,7 @@ def test_path_tables_hold_every_exact_hit_on_real_frames(checker, name, make, w,
             if m == 0:
                 whole = st
             else:  # the patches serve the rays the whole-sphere families served, with fewer candidates although their cells are coarser
-                assert st.members >= whole.members - 8 and st.candidates < whole.candidates
+                assert st.members >= whole.members - 8 and (wide or st.candidates < whole.candidates)  # (wide: 6 patches on cells twice as coarse)
 
 
 @pytest.mark.parametrize("m", [0, 1, 2, 3, 4])
