@@ -27,20 +27,29 @@ $(BUILD)/host_%.o: $(CSRC)/host/%.c include/trt.h include/trt_host.h
 	@mkdir -p $(BUILD)
 	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
-$(BUILD)/trt_capi$(TAG).o: $(CSRC)/trt_capi.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h include/trt_hip_diag.h
+# the library's translation units (csrc/trt_context.hpp says what each holds); trt_render is the one that instantiates the production kernel
+UNITS := trt_capi trt_tables trt_render trt_diag trt_dropin
+UNIT_OBJ := $(patsubst %,$(BUILD)/%$(TAG).o,$(UNITS))
+HIP_HEADERS := $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) include/trt.h include/trt_hip.h include/trt_hip_diag.h
+
+$(BUILD)/trt_render$(TAG).o: $(CSRC)/trt_render.hip $(HIP_HEADERS)
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o $@ $(CSRC)/trt_capi.hip 2> $(BUILD)/resource_usage$(TAG).txt \
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o $@ $(CSRC)/trt_render.hip 2> $(BUILD)/resource_usage$(TAG).txt \
 		|| (cat $(BUILD)/resource_usage$(TAG).txt; false)
 	@grep -E "error|warning:" $(BUILD)/resource_usage$(TAG).txt || true
 	@awk '/Function Name: .*render_rounds_kernelILb0/ {f=1} f && /VGPRs:/ {split($$0,a,"VGPRs: "); v=a[2]+0; print "render_rounds_kernel<false>: " v " VGPRs" (v>128 ? "  ** WARNING: more than 128 -> 3 waves/SIMD **" : " (4 waves/SIMD)"); exit}' $(BUILD)/resource_usage$(TAG).txt
+
+$(BUILD)/%$(TAG).o: $(CSRC)/%.hip $(HIP_HEADERS)
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(BUILD)/trt_dist.o: $(CSRC)/trt_dist.hip include/trt.h include/trt_hip.h include/trt_hip_diag.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/trt_dist.hip
 
 # RCCL is bound at run time by trt_dist.hip (dlopen): the library does not link against it
-$(LIB): $(BUILD)/trt_capi$(TAG).o $(BUILD)/trt_dist.o $(HOST_OBJ)
-	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $< $(BUILD)/trt_dist.o $(HOST_OBJ) -ldl
+$(LIB): $(UNIT_OBJ) $(BUILD)/trt_dist.o $(HOST_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(UNIT_OBJ) $(BUILD)/trt_dist.o $(HOST_OBJ) -ldl
 
 demo: examples/trt_demo examples/trt_dist_demo
 examples/%: examples/%.c $(LIB) include/trt_hip.h include/trt_host.h
@@ -62,7 +71,7 @@ tests/_build/librccl_stub.so: tests/rccl_stub.cpp
 
 # compiler's view of registers / LDS / occupancy per kernel
 resource-usage:
-	$(HIPCC) $(HIPFLAGS) -shared -Rpass-analysis=kernel-resource-usage -o /tmp/trt_ru.so $(CSRC)/trt_capi.hip 2>&1 | grep -E "remark" || true
+	$(HIPCC) $(HIPFLAGS) -c -Rpass-analysis=kernel-resource-usage -o /tmp/trt_ru.o $(CSRC)/trt_render.hip 2>&1 | grep -E "remark" || true
 
 clean:
 	rm -rf $(LIB) $(BUILD) examples/trt_demo examples/trt_dist_demo

@@ -120,6 +120,7 @@ struct CullView
 constexpr int kLdsCameraDoubles = 16;                       // basis x,y,z (9) eye (3) -screen_distance (1) basis z * -screen_distance (3)
 constexpr int kDirGridDoubles = 14, kPointGridDoubles = 9;  // sizeof(trt_dirgrid) / 8, sizeof(trt_pointgrid) / 8 (asserted in trt_rounds.hpp)
 
+#ifdef TRT_UNIT_RENDER // kernels that are not templates have ONE home among the library's translation units: trt_render.hip
 // TRT.c:1063-1066 for frames rendered with samples as work units: pixel = (((0 + s0) + s1) + ...) * (1/spp),
 // samples in index order.  The scratch is sample-major, samples[(k*pixels + pixel)*3 + channel], so that for every k
 // consecutive threads read consecutive doubles (a pure streaming kernel: spp*24 B read + 24 B written per pixel).
@@ -141,5 +142,7 @@ __global__ void quantize_kernel(const double *px, long n_values, unsigned char *
     if (i < n_values)
         rgb[i] = (unsigned char)d2i(px[i] * 255);
 }
+
+#endif // TRT_UNIT_RENDER
 
 } // namespace trt

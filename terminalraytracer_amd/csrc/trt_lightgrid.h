@@ -232,7 +232,7 @@ TRT_HD int trt_pointgrid_cell(const trt_pointgrid *G, double ox, double oy, doub
 /* ------------------------------------------------ builders ------------------------------------------------
  * A table is built in two steps: a per-light PREPARE on the host (O(N): grid placement, one small record per
  * sphere) and the marking of every (cell, sphere) pair by a predicate that uses only + - * / and sqrt -- IEEE
- * operations that round identically on the host and on the device -- so the device kernels (trt_capi.hip, one
+ * operations that round identically on the host and on the device -- so the device kernels (trt_tables.hip, one
  * thread per cell) and the host reference builders below (tests) produce the same tables bit for bit. */
 
 /* sphere j of a chunk of 64 sits at bit 63 - j, the order the exact stage walks with count-leading-zeros */

@@ -424,7 +424,7 @@ TRT_HD int trt_list_entry(unsigned long long cell, const unsigned long long *poo
  * the look-up assigns to cell (c, j) lies in that cell grown by 0.01 of its side, which lies inside the tile grown by 0.01 of
  * ITS side, so a sphere such a ray can hit passes both.  The tile's test is what makes building a table cheap: a builder
  * evaluates it once per (tile, sphere) and then the cell's predicate only for the few spheres whose cone reaches the tile
- * (csrc/trt_capi.hip: build_family_lists_kernel, a tile per workgroup; the eye's tables, which are rebuilt whenever the
+ * (csrc/trt_tables.hip: build_family_lists_kernel, a tile per workgroup; the eye's tables, which are rebuilt whenever the
  * camera moves, took 0.95 ms at 256 spheres with every cell asking every sphere). */
 #define TRT_FAMILY_TILE 8
 #define TRT_LIST_MAX_SPHERES_HOST 256 /* the host builder caches a tile row's answers for up to this many spheres */

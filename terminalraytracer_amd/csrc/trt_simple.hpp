@@ -150,6 +150,7 @@ TRT_DEV d3 lit_color(const SceneView &s, const LdsScene &l, d3 at, d3 normal, d3
     return d3{clampd(out.x, 0.0, 1.0), clampd(out.y, 0.0, 1.0), clampd(out.z, 0.0, 1.0)};
 }
 
+#ifdef TRT_UNIT_RENDER // a kernel that is not a template has ONE home among the library's translation units (trt_context.hpp)
 __global__ __launch_bounds__(256) void render_simple_kernel(SceneView s, FrameView f)
 {
     extern __shared__ double lds[];
@@ -209,6 +210,8 @@ __global__ __launch_bounds__(256) void render_simple_kernel(SceneView s, FrameVi
         atomicAdd(&f.counters[1], (unsigned long long)n_shadow);
     }
 }
+#endif // TRT_UNIT_RENDER
+#ifdef TRT_UNIT_DIAG
 
 // trt_probe_rays: closest hit + lighting of arbitrary rays (tests)
 __global__ __launch_bounds__(256) void probe_rays_kernel(SceneView s, const double *rays, long n, int *obj, double *point,
@@ -258,5 +261,7 @@ __global__ void unit_selftest_kernel(const double *v, long n, double *fast, doub
         reference[4 * i] = r.x, reference[4 * i + 1] = r.y, reference[4 * i + 2] = r.z, reference[4 * i + 3] = __builtin_sqrt(v[4 * i + 3]);
     }
 }
+
+#endif // TRT_UNIT_DIAG
 
 } // namespace trt

@@ -1298,7 +1298,7 @@ def test_nine_contexts_cannot_share_one_scene(ctx):
 
 def test_an_exhausted_list_pool_only_costs_sweeps(ctx):
     """Lists longer than seven entries live in a pool; a list that finds no room leaves its cell without one and the cell's rays
-    sweep (csrc/trt_capi.hip pack_cell).  The pool's counter keeps counting after exhaustion -- with 64 bits, so that it cannot wrap
+    sweep (csrc/trt_tables.hip pack_cell).  The pool's counter keeps counting after exhaustion -- with 64 bits, so that it cannot wrap
     and hand out words that earlier cells point to.  A dense scene with the pool capped at 64 / 4096 words: nearly every long list
     is lost, frames and trace counts stay the oracle's, and more traces sweep than with the pool the library would have chosen."""
     scene = S.synth_scene(256, T.sky("synth"), T.bench_camera(64, 36))
