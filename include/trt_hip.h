@@ -126,7 +126,8 @@ int trt_set_scene(trt_context *ctx, const Scene *scene);
  * one copy per device however many contexts render it (the frame slots of a trt_dist render different cameras of one scene at the
  * same time: TRT.c:1296-1306 builds the scene once, TRT.c:1327-1339 moves the camera per frame).  Only what depends on the camera
  * -- the two tables of the eye's families -- and the per-frame buffers are dst's own.  Both contexts must be of the same device;
- * up to 8 contexts per scene.  While tables are shared, the table setters (trt_set_light_grids / _slabs, trt_set_path_grids /
+ * up to 8 contexts per scene, all of them driven from ONE thread (the slots a scene's sharers take and give back are not locked: a
+ * trt_dist drives its frame slots from the thread that calls it).  While tables are shared, the table setters (trt_set_light_grids / _slabs, trt_set_path_grids /
  * _patches / _min_spheres) refuse on every sharer; trt_set_scene gives a context tables of its own again.  The refraction
  * extension's indices are per context (dst starts with none). */
 int trt_share_scene(trt_context *dst, trt_context *src);

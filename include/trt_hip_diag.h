@@ -18,8 +18,9 @@
 extern "C" {
 #endif
 
-/* Tests: cap the scene's part of the pool of long candidate lists at `words` 64-bit words (0 = automatic) from the next
- * trt_set_scene on; lists that find no room leave their cell without a list and its rays sweep -- frames stay bit-identical. */
+/* Tests: cap the scene's part of the pool of long candidate lists, and the part of every eye slot (the eye's two tables are
+ * rebuilt per camera into a part of their own), at `words` 64-bit words (0 = automatic) from the next trt_set_scene on; lists
+ * that find no room leave their cell without a list and its rays sweep -- frames stay bit-identical. */
 int trt_set_list_pool_words(trt_context *ctx, size_t words);
 
 /* Work counters of the LAST rendered frame (device atomics, only when enabled; off by default

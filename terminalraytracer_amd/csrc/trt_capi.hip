@@ -528,9 +528,13 @@ extern "C" int trt_set_light_slabs(trt_context *ctx, int directional_slabs, int 
         return fail(TRT_ERR_ARGUMENT, "light slabs %d, %d", directional_slabs, point_shells);
     if (const int shared = refuse_if_shared(ctx, "trt_set_light_slabs"))
         return shared;
+    const int slabs_before = ctx->dirgrid_slabs, shells_before = ctx->pointgrid_shells;
     ctx->dirgrid_slabs = directional_slabs;
     ctx->pointgrid_shells = point_shells;
-    return trt_set_light_grids(ctx, ctx->dirgrid_cells, ctx->pointgrid_cells);
+    const int rc = trt_set_light_grids(ctx, ctx->dirgrid_cells, ctx->pointgrid_cells);
+    if (rc) // the tables were not rebuilt: the context keeps the settings its tables were built with
+        ctx->dirgrid_slabs = slabs_before, ctx->pointgrid_shells = shells_before;
+    return rc;
 }
 
 extern "C" int trt_set_path_grids(trt_context *ctx, int eye_cells, int sphere_cells)

@@ -449,7 +449,8 @@ TRT_DEV uint32_t sky_texel_unit(const uint32_t *sky, int dim, d3 dir)
 // lies in (E, dim - E) and whose fractional part lies in (E, 1 - E) truncates to the reference's ui; everything else -- a
 // coordinate next to a texel's edge, next to the face's edge (where the clamp of TRT.c:760 acts) or NaN (a direction that is
 // not finite or not of FP32's range) -- is ambiguous.  A WRONG FACE needs two components whose magnitudes agree to 2^-23: then
-// |c| / best is within 2^-22 of 1 and U' within E of 0 or dim: ambiguous.  dim >= 2^20 makes everything ambiguous.
+// |c| / best is within 2^-22 of 1 and U' within E of 0 or dim: ambiguous.  dim >= 2^20 makes everything ambiguous, and so does a
+// direction whose largest component is below 2^-100 in magnitude (the instructions flush FP32 denormals).
 TRT_DEV long sky_index_estimate(int dim, float dim_f, d3 dir, bool &ambiguous)
 {
     const float x = (float)dir.x, y = (float)dir.y, z = (float)dir.z;
@@ -463,7 +464,10 @@ TRT_DEV long sky_index_estimate(int dim, float dim_f, d3 dir, bool &ambiguous)
     const float U = __builtin_fmaf(un, dim_f, half), V = __builtin_fmaf(vn, dim_f, half);
     const float fu = __builtin_amdgcn_fractf(U), fv = __builtin_amdgcn_fractf(V);
     const float lo = __builtin_fminf(__builtin_fminf(U, V), __builtin_fminf(fu, fv)), hi = __builtin_fmaxf(U - dim_f + 1.0f, __builtin_fmaxf(V - dim_f + 1.0f, __builtin_fmaxf(fu, fv)));
-    ambiguous = !(lo > e && hi < 1.0f - e); // NaN: ambiguous
+    // The cube instructions flush FP32 denormals: a direction whose LARGEST component is below 2^-100 (an un-normalised vector that
+    // TRT.c:444 left alone) may have lost a smaller one altogether while the reference's FP64 ratio keeps it -- ambiguous.  With the
+    // largest component above that, a component that flushes is below 2^-25 of it: inside E.
+    ambiguous = !(lo > e && hi < 1.0f - e) || !(__builtin_fabsf(ma) > 0x1p-100f); // NaN: ambiguous
     return ((long)face * dim + (long)(int)V) * dim + (long)(int)U;
 }
 

@@ -423,7 +423,12 @@ extern "C" int trt_dist_set_scene(trt_dist *d, const Scene *scene)
     { // the first slot builds the new scene's tables (its old ones stay alive until the last sharer has let go), the others share them
         const int rc = &s == &d->slots[0] ? trt_set_scene(s.ctx, scene) : trt_share_scene(s.ctx, d->slots[0].ctx);
         if (rc)
-            return dist_fail(rc, "%s: %s", &s == &d->slots[0] ? "trt_set_scene" : "trt_share_scene", trt_last_error());
+        { // some slots may hold the new scene and others the old one: frames would alternate between the two without an error.
+          // Nothing of this trt_dist can be trusted any more -- the same state a failed collective leaves (trt_hip.h).
+            d->poisoned = true;
+            return dist_fail(rc, "%s: %s (the renderer is unusable now: its frame slots may hold different scenes; destroy it)",
+                             &s == &d->slots[0] ? "trt_set_scene" : "trt_share_scene", trt_last_error());
+        }
     }
     return TRT_OK;
 }

@@ -100,7 +100,7 @@ static int refresh_default_scene(trt_context *ctx, const Scene *scene)
 // primitives differ from the previous call's on `moving_after` consecutive calls is treated as MOVING: its candidate tables are
 // rebuilt per call the cheap way (one family per sphere, no patches); after `still_after` consecutive unchanged calls the full
 // tables are built once.  moving_after = 0: never (every change builds the full tables).  Defaults 2 and 3.  Frames are
-// bit-identical either way.  *moving (may be NULL): whether the default context currently treats its scene as moving.
+// bit-identical either way.  trt_scene_is_moving() says whether the default context currently treats its scene as moving.
 extern "C" int trt_set_scene_policy(int moving_after, int still_after)
 {
     if (moving_after < 0 || still_after < 1)

@@ -280,6 +280,8 @@ static int build_light_grids(trt_context *ctx, const trt_cull_scene &cs)
     const size_t dir_cells = (size_t)sd * gd * gd, point_cells = 6 * (size_t)sp * gp * gp;
     HIP_TRY(ctx->T->d_dir_lists.reserve(dir_cells * nd));
     HIP_TRY(ctx->T->d_point_lists.reserve(point_cells * np));
+    HIP_TRY(hipMemsetAsync(ctx->T->d_dir_lists.ptr, 0xFF, std::max<size_t>(dir_cells * nd, 1) * sizeof(unsigned long long), ctx->stream)); // unwritten = "no list"
+    HIP_TRY(hipMemsetAsync(ctx->T->d_point_lists.ptr, 0xFF, std::max<size_t>(point_cells * np, 1) * sizeof(unsigned long long), ctx->stream));
     if (nd)
         hipLaunchKernelGGL(pack_lists_kernel, dim3((unsigned)((dir_cells * nd + block - 1) / block)), dim3(block), 0, ctx->stream, ctx->T->d_dir_masks.ptr,
                            (long)(dir_cells * nd), (int)words, ctx->T->d_dir_lists.ptr, ctx->T->d_pool.ptr, ctx->T->d_pool_used.ptr, (unsigned)ctx->T->pool_scene_words, bits);
@@ -344,6 +346,10 @@ static int build_path_tables(trt_context *ctx, const trt_cull_scene &cs, const d
     if (eye_part + families * sph_cells >= 0xffffffffull)
         return fail(TRT_ERR_CAPACITY, "path tables of %zu families x %zu cells", families, sph_cells);
     HIP_TRY(ctx->T->d_path_lists.reserve(eye_part + families * sph_cells));
+    // A cell that no builder has written must not look like a list: 0xFF.. is TRT_LIST_NONE ("no list": the ray's wave sweeps),
+    // whereas the bytes hipMalloc hands out could read as a pooled list at any offset of the pool -- a wild read in the render
+    // kernel (round 4's "nopack" experiment).  Every cell IS written before a kernel reads it; this is the belt.
+    HIP_TRY(hipMemsetAsync(ctx->T->d_path_lists.ptr, 0xFF, (eye_part + families * sph_cells) * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx->T->d_families.reserve(std::max<size_t>(families, 1)));
     HIP_TRY(ctx->T->d_sphere_fam.reserve(4 * (size_t)std::max(n, 1)));
     HIP_TRY(ctx->T->d_patch_rec.reserve(P * TRT_PATCH_RECORD));
@@ -403,8 +409,11 @@ int build_tables(trt_context *ctx, const trt_cull_scene &cs, const double *groun
     // (Round 4 gave them one word per cell: enough at 64 and 256 spheres, not in a scene of 700, whose primary rays then swept.)
     const size_t per_word = wide == 2 ? 4 : 8;
     ctx->T->pool_eye_words = std::max<size_t>(1024, 2 * 6 * ge * ge * std::min<size_t>((n + per_word - 1) / per_word, 64));
-    if (ctx->list_pool_cap) // trt_set_list_pool_words (tests: the pool's exhaustion)
+    if (ctx->list_pool_cap) // trt_set_list_pool_words (tests: the pool's exhaustion -- of the scene's part and of every eye slot's)
+    {
         ctx->T->pool_scene_words = std::min(ctx->T->pool_scene_words, std::max<size_t>(ctx->list_pool_cap, 1));
+        ctx->T->pool_eye_words = std::min(ctx->T->pool_eye_words, std::max<size_t>(ctx->list_pool_cap, 1));
+    }
     const double t0 = host_seconds();
     int rc = TRT_OK;
     // The scene's part is sized by a guess (a word per cell) and GROWN to what the builders asked for if that was more: the

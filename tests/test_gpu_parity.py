@@ -1327,6 +1327,47 @@ def test_an_exhausted_list_pool_only_costs_sweeps(ctx):
         c.close()
 
 
+def test_an_exhausted_eye_table_pool_only_costs_sweeps(ctx):
+    """The eye's two tables are rebuilt for every camera on the frame's stream, their long lists into a part of the pool of their
+    own whose counter nobody reads back.  With that part capped at 16 words nearly every long list of the eye's tables finds no
+    room: pack_cell's limit turns those cells into "no list" (never into a list at an offset beyond the part), the primary rays
+    and the ground's reflections of them sweep, and frames and trace counts of a MOVING camera stay the oracle's.  (Round 4's
+    "nopack" experiment faulted in the render kernel on cells that no builder had written; cells now start out as "no list".)"""
+    scene = S.synth_scene(256, T.sky("synth"), T.bench_camera(64, 36))
+    big = scene.spheres.copy()
+    big[:, 3] *= 1.6  # fat, overlapping spheres: long lists everywhere
+    scene = scene.with_spheres(big)
+    c = hip.Context(0)
+    try:
+        c.enable_counters(True)
+        swept = {}
+        for cap in (0, 16):
+            c.set_list_pool_words(cap)
+            c.set_path_patches(0)  # the scene's own part is capped alike: one family per sphere keeps the comparison about the eye
+            c.set_scene(scene)
+            swept[cap] = 0
+            for t in (1.0, 2.5, 10.0):  # a new eye, new eye tables, the same capped part
+                cam = T.bench_camera(64, 36, t)
+                moved = scene.with_camera(cam)
+                want, st = T.oracle_render(moved, 64, 36, 4, 2)
+                got = c.render_host(cam, hip.RowSet.whole(64, 36), 4, 2)
+                assert np.array_equal(bits(got), bits(want)), (cap, t)
+                assert c.read_counters() == (st.path_rays, st.shadow_rays)
+                swept[cap] += c.read_diagnostics()["swept_traces"]
+                info, cells, pool = c.read_path_tables(cam)
+                eye_cells = cells[:2 * 6 * info["eye_cells"] ** 2]
+                lost = sum(1 for x in eye_cells if (int(x) >> 56) == 0xFF)
+                if cap:
+                    assert info["pool_used_eye"] > cap and lost > 1000, (info, lost)  # the counter went on counting; the lists say so
+                    at = [int(x) & 0xFFFFFFFF for x in eye_cells if ((int(x) >> 56) & 0x80) and (int(x) >> 56) != 0xFF]
+                    assert all(a < info["pool_capacity"] for a in at)  # what lists there are lie inside the pool
+                else:
+                    assert lost == 0, lost
+        assert swept[16] > swept[0], swept
+    finally:
+        c.close()
+
+
 def test_a_scene_that_changes_with_every_call_of_the_drop_in_entry(ctx):
     """project_scene is a pure function of *scene (TRT.c:966): a caller may move a sphere before EVERY call.  The drop-in layer then
     stops building the full tables (24 patches per sphere at 256 spheres: ~0.1 s) and builds the cheap ones (one family per sphere)
@@ -1474,6 +1515,11 @@ def test_the_sky_estimate_vouches_only_for_the_reference_index(ctx):
         axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 1], [-1, -1, -1], [1, -1, 0], [0, 1, -1]], dtype=np.float64)
         dirs = np.concatenate([v, cube, edge, axes])
         dirs = dirs / np.linalg.norm(dirs, axis=1, keepdims=True)
+        # directions that were never normalised (TRT.c:444 leaves vectors shorter than 1e-4 alone) down among FP32's denormals,
+        # some with one component a few thousand times smaller than the others: the cube instructions flush what the FP64 form keeps
+        tiny = v[:60_000] * 10.0 ** rng.uniform(-46, -28, size=(60_000, 1))
+        tiny[::3, rng.integers(0, 3)] *= 10.0 ** rng.uniform(-4, -1)
+        dirs = np.concatenate([dirs, tiny])
         exact, est, amb = ctx.selftest_sky(dirs, dim)
         sure = amb == 0
         assert np.array_equal(exact[sure], est[sure]), (dim, int((exact[sure] != est[sure]).sum()))
