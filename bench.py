@@ -503,12 +503,22 @@ def main():
     for i in range(args.warmup):
         render(camera_of(i))
     barrier()
+    launched_before = [c.launch_count() for c in contexts]
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
         last = render(camera_of(i))
     barrier()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=carrier)
+    # the same loop by the DEVICE's clock: from the start of the first timed launch to the end of the last one (HIP events on the
+    # contexts' streams; the frames take turns over the contexts, so the earliest start and the latest end are found pairwise)
+    device_span_ms = None
+    try:
+        took = [(c, a, c.launch_count()) for c, a in zip(contexts, launched_before) if c.launch_count() > a]
+        if took and sum(b - a for _, a, b in took) == args.steps:
+            device_span_ms = max(c0.launch_span_ms(a0, c1, b1 - 1) for c0, a0, _ in took for c1, _, b1 in took)
+    except hip.TrtError:
+        device_span_ms = None  # more launches per context than the event ring holds (--steps in the thousands)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     seconds = float(elapsed.item())
@@ -628,7 +638,16 @@ def main():
             # one frame at a time (no overlap between consecutive frames): render kernel + ordered mean, HIP events per launch
             "one_frame_at_a_time": {"render_kernel_ms": render_ms_avg, "reduce_kernel_ms": reduce_ms_avg, "launches": d1,
                                     "path_rays_per_s": path_mean / ((render_ms_avg + reduce_ms_avg) * 1e-3)},
+            # the timed loop by the device's own clock (HIP events, first launch's start to last launch's end): frames overlap, so this is
+            # what a frame costs the GPU in the pipelined loop; it must not exceed ms_per_step (which adds the host's part of the loop)
+            "device_ms_per_step": device_span_ms / args.steps if device_span_ms is not None else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # what actually bounds the kernel: the issue of vector instructions, most of them per-ray FP64
+                         # geometry.  COMMITTED counters of this kernel (profiles/traffic.json), not measured in this run.
+                         "bound_actual": "valu_issue",
+                         "valu_busy": ((prof or {}).get("valu") or {}).get("valu_busy_measured"),
+                         "fp64_share": ((prof or {}).get("compute_executed") or {}).get("fp64_share_of_valu_instructions"),
+                         "issue_frac": (compute_executed((prof or {}).get("compute_executed"), render_ms_avg) or {}).get("issue_frac"),
                          "traffic": (prof or {}).get("hbm_bytes_per_launch"),
                          "traffic_source": (prof or {}).get("source"),
                          "profile": profile_identity(prof),
@@ -647,8 +666,11 @@ def main():
             # in `valu` (instructions, measured VALU busy).
             "compute": {"basis": "reference-equivalent FP64 flops = trace_ray calls x (25 N + 17)",
                         "flops_per_frame": (path_mean + float(np.mean(shadow_cam))) * (25 * wl["spheres"] + 17),
-                        "achieved": (path_mean + float(np.mean(shadow_cam))) * (25 * wl["spheres"] + 17) / (render_ms_avg * 1e-3) / 1e12,
-                        "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS, "peak_without_fma": FP64_PEAK_WITHOUT_FMA,
+                        # NOT a rate of executed work and not to be set against a peak: the reference's flops for these rays over the
+                        # kernel's duration.  The tables avoid most of them (roofline.compute_executed is what the hardware did).
+                        "reference_equivalent_tflops": (path_mean + float(np.mean(shadow_cam))) * (25 * wl["spheres"] + 17) / (render_ms_avg * 1e-3) / 1e12,
+                        "unit": "TFLOP/s of the REFERENCE's algorithm, mostly avoided rather than executed",
+                        "fp64_vector_peak_for_orientation": FP64_PEAK_TFLOPS,
                         "peak_source": "MI355X FP64 vector: half the 157.3 TFLOP/s FP32 vector figure of MI355X_MICROARCH.md; -ffp-contract=off halves it again"},
             "valu": (prof or {}).get("valu"),
             "kernel_info": ctx0.kernel_info(),

@@ -106,6 +106,14 @@ int trt_probe_rays(trt_context *ctx, const Ray *rays, size_t n, int *obj, double
 int trt_probe_rays_production(trt_context *ctx, const Camera *camera, const Ray *rays, const int *families, size_t n, int *obj,
                               double *point, double *normal, double *material, double *lit);
 
+/* Measurement: the number of frames a context has launched so far (launch numbers count from 0), and the DEVICE time in ms from the
+ * start of launch `first_launch` of context `first` to the end -- render kernel and ordered mean -- of launch `last_launch` of
+ * context `last` (HIP events on the contexts' streams; both of one device; each among the last 256 launches of its context).
+ * A pipelined loop deals its frames over several contexts: span / frames is its device time per frame, which bench.py prints
+ * beside the host-clocked ms_per_step. */
+long trt_launch_count(trt_context *ctx);
+int trt_launch_span_ms(trt_context *first, long first_launch, trt_context *last, long last_launch, float *ms);
+
 /* TEST HOOK: allow (1) or forbid (0, the default) the environment variable TRT_RCCL_LIB to name the library that trt_dist_* binds in
  * RCCL's place (tests/rccl_stub.cpp: send / recv through shared memory, so that several ranks can share the one GPU of a test
  * box).  Must be called before the process's first use of RCCL: fails with TRT_ERR_NOT_INITIALISED once RCCL has been bound.  A

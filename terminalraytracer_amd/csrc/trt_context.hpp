@@ -230,8 +230,10 @@ struct trt_context
     int kernel = 0; // 0 production (persistent waves, synchronous rounds), 1 reference-order
     int rounds_blocks_per_cu = 0;
     int compact_blocks_per_cu = 0; // the same for the kernel with shading rings in LDS
+    int big_blocks_per_cu = 0;     // ... and for the plain rounds in 1024-thread workgroups (render_rounds_kernel<.., BIG>; 0: not available)
     long last_units = 0;           // samples of the most recent launch (trt_render_variant / trt_kernel_info describe that launch's kernel)
     bool last_compact = false;     // the most recent launch ran the kernel with the shading decoupled
+    bool last_big = false;         // ... the plain rounds in 1024-thread workgroups
     int compaction = -1;           // trt_set_compaction: -1 when it costs no occupancy, 0 never, 1 whenever the rings fit
     size_t occupancy_for_lds = (size_t)-1;
     hipEvent_t ev_chunk[16]; // hand-over of framebuffer chunks to the host copy threads (trt_render_host)
@@ -310,6 +312,14 @@ inline bool print_host_times()
 {
     static const bool on = getenv("TRT_PRINT_HOST_TIMES") != nullptr;
     return on;
+}
+
+// Does a frame run the plain rounds in 1024-thread workgroups (render_rounds_kernel<.., BIG>)?  When the scene has patches, no
+// counters are asked for, and sixteen waves around ONE image are more than the 256-thread workgroups that fit the CU's LDS hold.
+inline bool renders_big(const trt_context *ctx)
+{
+    return ctx->kernel == 0 && !ctx->ior_count && !ctx->counters_enabled && ctx->grids.path_enabled && ctx->grids.patch_m > 0 &&
+           ctx->big_blocks_per_cu * trt::kCompactBlock > ctx->rounds_blocks_per_cu * trt::kPersistentBlock;
 }
 
 inline bool rowset_valid(const trt_rowset *r)

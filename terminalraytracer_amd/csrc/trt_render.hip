@@ -31,6 +31,13 @@ int refresh_occupancy(trt_context *ctx)
                                                                  compact_lds_bytes(ctx, 64)));
             ctx->compact_blocks_per_cu = blocks;
         }
+        ctx->big_blocks_per_cu = 0;
+        if (ctx->rounds_blocks_per_cu < 4) // the image no longer fits four times: one image for sixteen waves instead
+        {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false, false, false, true, true>, trt::kCompactBlock,
+                                                                 image_lds_bytes(ctx, 64)));
+            ctx->big_blocks_per_cu = blocks;
+        }
     }
     return TRT_OK;
 }
@@ -88,6 +95,7 @@ void allow_large_lds_render(const trt_context *ctx)
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
+    (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
     (void)hipFuncSetAttribute((const void *)trt::render_rounds_kernel<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit);
@@ -253,6 +261,14 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
             const long want = (units + trt::kCompactBlock - 1) / trt::kCompactBlock;
             pl = trt::PersistentLaunch{(unsigned)std::max(1L, std::min(want, cap)), (unsigned)trt::kCompactBlock};
         }
+        const bool big = !compact && renders_big(ctx);
+        if (big)
+        {
+            const long cap = (long)(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0)) * ctx->big_blocks_per_cu;
+            const long want = (units + trt::kCompactBlock - 1) / trt::kCompactBlock;
+            pl = trt::PersistentLaunch{(unsigned)std::max(1L, std::min(want, cap)), (unsigned)trt::kCompactBlock};
+        }
+        ctx->last_big = big;
         const size_t plds = image_lds_bytes(ctx, rays_per_pixel);
         const dim3 grid(pl.grid), block(pl.block);
         if (ctx->ior_count && ctx->ior_count != ctx->scene.num_spheres) // before the first event of the launch is recorded
@@ -283,6 +299,8 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         }
         else if (patches && ctx->counters_enabled)
             hipLaunchKernelGGL((trt::render_rounds_kernel<true, false, false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
+        else if (patches && big)
+            hipLaunchKernelGGL((trt::render_rounds_kernel<false, false, false, true, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         else if (patches)
             hipLaunchKernelGGL((trt::render_rounds_kernel<false, false, false, true>), grid, block, plds, stream, ctx->scene, ctx->cull, f, ctx->grids);
         else if (ctx->counters_enabled)
@@ -486,6 +504,26 @@ extern "C" int trt_render_kernel_times(trt_context *ctx, float *render_ms, float
     return (int)n;
 }
 
+// trt_hip_diag.h: how many frames the context has launched, and the device time from the START of launch `first_launch` of context
+// `first` to the END (render kernel and ordered mean) of launch `last_launch` of context `last` -- the span of a pipelined loop
+// whose frames take turns over several contexts.  Launch numbers count from 0; the contexts keep the events of their last 256.
+extern "C" long trt_launch_count(trt_context *ctx) { return ctx ? ctx->launches : -1; }
+
+extern "C" int trt_launch_span_ms(trt_context *first, long first_launch, trt_context *last, long last_launch, float *ms)
+{
+    if (!first || !last || !ms || first->device != last->device)
+        return fail(TRT_ERR_ARGUMENT, "bad argument");
+    if (first_launch < 0 || first_launch >= first->launches || first->launches - first_launch > kEventRing || last_launch < 0 ||
+        last_launch >= last->launches || last->launches - last_launch > kEventRing)
+        return fail(TRT_ERR_ARGUMENT, "launches %ld / %ld are not among the last %d of their contexts (%ld / %ld launched)", first_launch, last_launch,
+                    kEventRing, first->launches, last->launches);
+    HIP_TRY(hipSetDevice(first->device));
+    HIP_TRY(hipStreamSynchronize(first->stream));
+    HIP_TRY(hipStreamSynchronize(last->stream));
+    HIP_TRY(hipEventElapsedTime(ms, first->ev_start[first_launch % kEventRing], last->ev_stop[last_launch % kEventRing]));
+    return TRT_OK;
+}
+
 extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *static_lds_bytes, int *max_blocks_per_cu,
                                int *compute_units)
 {
@@ -494,8 +532,10 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
     HIP_TRY(hipSetDevice(ctx->device));
     const bool decoupled = ctx->have_scene && (ctx->last_units > 0 ? ctx->last_compact : renders_decoupled(ctx, kCompactionMinUnits));
     const bool patches = ctx->have_scene && ctx->grids.path_enabled && ctx->grids.patch_m > 0;
+    const bool big = !decoupled && renders_big(ctx);
     const void *fn = ctx->kernel == 1 ? (const void *)trt::render_simple_kernel
                      : decoupled      ? (const void *)trt::render_rounds_kernel<false, false, true>
+                     : big            ? (const void *)trt::render_rounds_kernel<false, false, false, true, true>
                      : patches        ? (const void *)trt::render_rounds_kernel<false, false, false, true>
                                       : (const void *)trt::render_rounds_kernel<false>;
     hipFuncAttributes attr;
@@ -514,6 +554,8 @@ extern "C" int trt_kernel_info(trt_context *ctx, int *vgprs, int *sgprs, int *st
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_simple_kernel, 256, lds));
         else if (decoupled)
             blocks = ctx->compact_blocks_per_cu; // workgroups of kCompactBlock threads
+        else if (big)
+            blocks = ctx->big_blocks_per_cu; // likewise
         else
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false>, trt::kPersistentBlock, lds));
         *max_blocks_per_cu = blocks;

@@ -976,11 +976,15 @@ constexpr int kCompactBlock = 1024;
 // PATCHES: the path rays' tables have a family per PATCH of a sphere's surface (GridView::patch_m > 0, trt_raygrid.h) instead of
 // one per sphere: another look-up (path_cell_patches), the same everything else.  Its own instantiation, so that scenes
 // without patches run the code -- and the register allocation -- they ran before there were any.
-template <bool COUNT, bool REFRACT = false, bool COMPACT = false, bool PATCHES = false>
-__global__ __launch_bounds__(COMPACT ? kCompactBlock : kPersistentBlock, (COMPACT && !COUNT && kCompactBlock == 1024) ? 4 : TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
+// BIG (round 5): the plain rounds in workgroups of 1024 threads -- ONE LDS image per CU, shared by sixteen waves -- for scenes whose
+// image no longer fits four times into a CU's 160 KB (above ~290 spheres: 136 bytes a sphere): with 256-thread workgroups such a
+// scene runs three, two, one wave per SIMD (512 spheres: two).  Same code; the register allocator has to stay under 128.
+template <bool COUNT, bool REFRACT = false, bool COMPACT = false, bool PATCHES = false, bool BIG = false>
+__global__ __launch_bounds__((COMPACT || BIG) ? kCompactBlock : kPersistentBlock, (((COMPACT && !COUNT) || BIG) && kCompactBlock == 1024) ? 4 : TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
 {
     static_assert(!(REFRACT && COMPACT), "the refraction extension runs on the plain rounds");
     static_assert(!(PATCHES && COMPACT), "scenes with patches run the plain rounds");
+    static_assert(!BIG || (PATCHES && !COUNT && !REFRACT && !COMPACT), "1024-thread workgroups: the shipping patch instantiation only");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const LdsImage L = stage_lds_image(lds, s, cull, f, grids);
     const int n = s.num_spheres, nd = s.num_dir, nl = s.num_dir + s.num_point;

@@ -99,6 +99,8 @@ SYMBOLS = {
     "trt_selftest_div_sqrt": (_I, [_VP, _VP, _VP, _SZ, _VP, _VP]),
     "trt_probe_rays": (_I, [_VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
     "trt_probe_rays_production": (_I, [_VP, C.POINTER(L.Camera), _VP, _VP, _SZ, _VP, _VP, _VP, _VP, _VP]),
+    "trt_launch_count": (C.c_long, [_VP]),
+    "trt_launch_span_ms": (_I, [_VP, C.c_long, _VP, C.c_long, C.POINTER(C.c_float)]),
     "trt_dist_unique_id": (_I, [_VP]),
     "trt_dist_frame_times": (_I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "trt_dist_allow_rccl_override": (_I, [_I]),
@@ -368,6 +370,16 @@ class Context:
         if n < 0:
             _check(n)
         return [a[i] for i in range(n)], [b[i] for i in range(n)]
+
+    def launch_count(self):
+        """frames this context has launched so far (trt_launch_count)"""
+        return int(lib().trt_launch_count(self._h))
+
+    def launch_span_ms(self, first_launch, last, last_launch):
+        """device ms from the start of this context's launch `first_launch` to the end of context `last`'s launch `last_launch` (trt_launch_span_ms)"""
+        ms = C.c_float()
+        _check(lib().trt_launch_span_ms(self._h, first_launch, last._h, last_launch, C.byref(ms)))
+        return float(ms.value)
 
     def enable_counters(self, on=True):
         _check(lib().trt_enable_counters(self._h, 1 if on else 0))

@@ -870,6 +870,15 @@ def test_scenes_of_more_than_256_spheres_keep_their_tables(ctx, n):
                 assert diag["swept_traces"] < 0.05 * 3 * diag["wave_loop_trips"], (n, path_cells, m, diag)
             elif light_cells == (128, 64):  # beyond 1024 spheres the path rays sweep, the shadow rays read lists
                 assert diag["wave_loop_trips"] <= diag["swept_traces"] < 2 * diag["wave_loop_trips"], diag
+        # The library's own settings, no counters: scenes whose LDS image no longer fits four times per CU (from ~290 spheres) run the
+        # plain rounds in 1024-thread workgroups, one image for sixteen waves (render_rounds_kernel<.., BIG>) -- the same frame.
+        ctx.enable_counters(False)
+        ctx.set_light_grids(128, 64)
+        ctx.set_path_patches(-1)
+        ctx.set_path_grids(64, 32)
+        got = render(ctx, scene, 72, 40, 6, 4)
+        assert np.array_equal(bits(got), bits(want)), n
+        assert ctx.render_variant()["workgroup_threads"] == (1024 if 290 < n <= 1024 else 256), (n, ctx.render_variant())
     finally:
         ctx.enable_counters(False)
         ctx.set_light_grids(128, 64)
