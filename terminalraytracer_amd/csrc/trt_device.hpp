@@ -59,9 +59,31 @@ TRT_DEV bool mid_range(double x) { return hi32(x) - (723u << 20) < (600u << 20);
 #ifndef TRT_LEAN_SQRT
 #define TRT_LEAN_SQRT 1
 #endif
+#ifndef TRT_OPT_SQRT_FIXUP
+#define TRT_OPT_SQRT_FIXUP 1 // the short way first, the compiler's sequence as a rare fix-up behind ONE forward branch (no diamond)
+#endif
 TRT_DEV double sqrt_exact(double x) // == __builtin_sqrt(x)
 {
-#if TRT_LEAN_MATH && TRT_LEAN_SQRT
+#if TRT_LEAN_MATH && TRT_LEAN_SQRT && TRT_OPT_SQRT_FIXUP
+    // the steps of the compiler's expansion between its scaling and its 0/inf select, for every lane; a lane outside the window gets
+    // garbage from them and, in the rare wave that has such a lane, the compiler's full sequence instead
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    double root = __builtin_fma(d, h, g);
+    const bool outside = !mid_range(x);
+    if (__builtin_expect(__any(outside), 0))
+    {
+        const double full = __builtin_sqrt(x);
+        root = outside ? full : root;
+    }
+    return root;
+#elif TRT_LEAN_MATH && TRT_LEAN_SQRT
     if (TRT_LIKELY(!__any(!mid_range(x))))
     { // the steps of the compiler's expansion between its scaling and its 0/inf select
         const double y = __builtin_amdgcn_rsq(x);
@@ -74,8 +96,10 @@ TRT_DEV double sqrt_exact(double x) // == __builtin_sqrt(x)
         d = __builtin_fma(-g, g, x);
         return __builtin_fma(d, h, g);
     }
-#endif
     return __builtin_sqrt(x);
+#else
+    return __builtin_sqrt(x);
+#endif
 }
 
 // TRT.c:439-450: sqrt of the squared length, then THREE divisions, only when length > 1e-4

@@ -45,6 +45,16 @@
 #ifndef TRT_OPT_POOLCHECK
 #define TRT_OPT_POOLCHECK 1 // the exact loops ask the lanes for a pool word only in the iterations that can need one
 #endif
+#ifndef TRT_OPT_EXPECT
+#define TRT_OPT_EXPECT 1 // the whole-wave sweep and the closest-hit search of a point light are the rare ways: laid out as such
+#endif
+#if TRT_OPT_EXPECT
+#define TRT_EXPECT_LIST(c) __builtin_expect(!!(c), 1)
+#define TRT_EXPECT_RARE(c) __builtin_expect(!!(c), 0)
+#else
+#define TRT_EXPECT_LIST(c) (c)
+#define TRT_EXPECT_RARE(c) (c)
+#endif
 #ifndef TRT_OPT_BZSZ
 #define TRT_OPT_BZSZ 1
 #endif
@@ -313,7 +323,7 @@ TRT_DEV Hit trace(const LdsImage &L, const CullView &cull, int n, d3 o, d3 d, bo
     if (!TRT_OPT_DIRCONST)
         shared_ad = nullptr;
     const double a = shared_ad ? shared_ad[0] : dot(d, d);
-    if (use_list)
+    if (TRT_EXPECT_LIST(use_list))
     {
         const unsigned ctl = (unsigned)(cell >> 56);
         bool pooled = (ctl & TRT_LIST_POOLED) != 0;
@@ -822,7 +832,7 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
                 full = __any(lit_lanes && unsure);
                 TRT_STAMP_AT(17); // any-hit search
             }
-            if (full)
+            if (TRT_EXPECT_RARE(full))
             {
                 if (COUNT)
                     tally.full++;
