@@ -5,6 +5,8 @@ modes: "" generic | wide | lights | compact (decoupled shading forced on) | refr
 dense: 128..256 spheres packed tightly, the library's default patches (or 6 / 54 / 96) |
 patches / patches_refract: a family per PATCH of a sphere's surface (trt_set_path_patches 1..4, random table resolutions, the
 three scene generators in turn), tables for every scene. |
+many: 257..1100 spheres (round 5: 16-bit list entries in every table, the wide family builder, 1024-thread workgroups above ~290
+spheres; beyond 1024 the path rays sweep), the library's defaults or one family per sphere / 6 patches / coarse tables. |
 sky: few small spheres, cubemaps of any side (1 ... 1031 texels, powers of two and not, procedural: every texel its own colour), the
 camera turned anywhere and placed anywhere (the skybox look-up's FP32 estimate and its FP64 fall-back, csrc/trt_device.hpp)."""
 import os, sys
@@ -81,6 +83,29 @@ def dense_scene(rng, w, h):
     return S.SceneData(sph, ground, d, p, cam, T.sky("synth"))
 
 
+def many_scene(rng, w, h):
+    """257..1100 spheres in a box like SYNTH-v0's or larger, duplicates and a few huge spheres among them."""
+    n = int(rng.choice([257, 258, 300, 320, 511, 512, 513, 700, 1023, 1024, 1025, 1100]))
+    box = rng.uniform(3.0, 12.0)
+    sph = np.zeros((n, 9))
+    sph[:, :3] = rng.uniform(-1, 1, (n, 3)) * [box, box * 0.4, box] + [0.0, 0.5, 0.0]
+    sph[:, 3] = rng.uniform(0.05, 0.5, n) * rng.choice([0.5, 1.0, 2.0])
+    sph[:, 4:7] = rng.uniform(0, 1, (n, 3))
+    sph[:, 7] = rng.choice([0.0, 0.3, 0.8, 1.0], n)
+    sph[:, 8] = 100.0
+    if rng.integers(0, 3) == 0:
+        sph[n - 1] = sph[0]          # exact twins at the two ends of the index range: the first index must win the tie
+        sph[n // 2, 3] = box * 0.3   # one sphere that is in nearly every list
+    ground = S.demo_ground().copy()
+    if rng.integers(0, 3) == 0:
+        ground[3:6] = [rng.normal() * 0.2, 1.0, rng.normal() * 0.2]
+    ground[9] = rng.choice([0.0, 0.2, 0.9])
+    d, p = S.demo_lights()
+    cam = T.bench_camera(w, h, float(rng.choice([0.0, 0.5, 1.0, 2.5, 10.0])))
+    cam[9:12] *= rng.uniform(0.3, 2.0)
+    return S.SceneData(sph, ground, d, p, cam, T.sky("synth"))
+
+
 def sky_scene(rng, w, h):
     """Most rays end on the sky: 0..4 small spheres, a ground that may face away, a cubemap of a random side whose texels all
     differ, a camera with a random orthonormal basis somewhere near or far from the origin."""
@@ -105,7 +130,7 @@ def sky_scene(rng, w, h):
 
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
-make = {"wide": wide_scene, "lights": light_heavy_scene, "compact": light_heavy_scene, "dense": dense_scene, "sky": sky_scene}.get(mode, P._fuzz_scene)
+make = {"wide": wide_scene, "lights": light_heavy_scene, "compact": light_heavy_scene, "dense": dense_scene, "sky": sky_scene, "many": many_scene}.get(mode, P._fuzz_scene)
 patches = mode.startswith("patches")
 refract = mode in ("refract", "patches_refract")  # EXTENSION, parity unpinned: against the oracle's restatement of the extension, not the reference
 bad = 0
@@ -119,6 +144,10 @@ with hip.Context(0) as ctx:
             w, h, spp = min(w, 96), min(h, 54), int(rng.choice([1, 3]))
             ctx.set_path_patches(-1 if seed % 3 else int(rng.choice([1, 3, 4])))
             ctx.set_path_grids(64, 32 if seed % 3 else 8)
+        if mode == "many":  # small frames (the oracle tests every sphere): the library's defaults one time in two, else other tables
+            w, h, b, spp = min(w, 64), min(h, 36), min(b, 6), int(rng.choice([1, 3]))
+            ctx.set_path_patches(-1 if seed % 2 else int(rng.choice([0, 1])))
+            ctx.set_path_grids(64 if seed % 2 else int(rng.choice([9, 64])), 32 if seed % 2 else int(rng.choice([3, 8, 16])))
         if seed % 2 == 0:  # round 4: the light tables' depth coordinate (slabs along a directional light, shells about a point light)
             ctx.set_light_slabs(int(rng.choice([1, 3, 16, 64])), int(rng.choice([1, 5, 16, 64])))
         if mode == "compact" and seed % 3 == 0:
