@@ -63,6 +63,21 @@ namespace trt
 {
 
 
+#define CONSTANT_AS __attribute__((address_space(4)))
+// whole 64-bit words through the constant address space: scalar loads (the kernel's arguments; wave-uniform records)
+template <class T>
+TRT_DEV T load_kernel_argument(const char CONSTANT_AS *at)
+{
+    static_assert(sizeof(T) % 8 == 0 && alignof(T) == 8, "argument structs are whole 64-bit words");
+    T out;
+    const unsigned long long CONSTANT_AS *src = (const unsigned long long CONSTANT_AS *)at;
+    unsigned long long *dst = (unsigned long long *)&out;
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 8; i++)
+        dst[i] = src[i];
+    return out;
+}
+
 // Candidate tables.  Every table cell is one 64-bit LIST CELL (trt_raygrid.h): up to seven sphere indices inline, longer
 // lists in `pool`.
 struct GridView
@@ -900,7 +915,6 @@ constexpr int kRingDoubles = 7 * kRingTasks + kRingTasks / 2 + 3 * 64; // point(
 // tenth of the VALU instructions.  TRT_FRESH_ARGS re-reads, at the head of a stage, the arguments that stage uses (the copies
 // shadow the kernel's parameters; unused fields are never loaded): a few s_load per stage instead of the v_readlanes, and
 // nothing to keep alive between stages.  The empty asm makes the pointer opaque so that the loads stay where they are written.
-#define CONSTANT_AS __attribute__((address_space(4)))
 constexpr size_t kArgScene = 0;
 constexpr size_t kArgCull = (kArgScene + sizeof(SceneView) + alignof(CullView) - 1) / alignof(CullView) * alignof(CullView);
 constexpr size_t kArgFrame = (kArgCull + sizeof(CullView) + alignof(FrameView) - 1) / alignof(FrameView) * alignof(FrameView);
@@ -916,18 +930,6 @@ struct RenderKernelArguments
 static_assert(offsetof(RenderKernelArguments, cull) == kArgCull && offsetof(RenderKernelArguments, f) == kArgFrame &&
                   offsetof(RenderKernelArguments, grids) == kArgGrids,
               "TRT_FRESH_ARGS reads the kernel's arguments at these offsets");
-template <class T>
-TRT_DEV T load_kernel_argument(const char CONSTANT_AS *at)
-{
-    static_assert(sizeof(T) % 8 == 0 && alignof(T) == 8, "argument structs are whole 64-bit words");
-    T out;
-    const unsigned long long CONSTANT_AS *src = (const unsigned long long CONSTANT_AS *)at;
-    unsigned long long *dst = (unsigned long long *)&out;
-#pragma unroll
-    for (size_t i = 0; i < sizeof(T) / 8; i++)
-        dst[i] = src[i];
-    return out;
-}
 // A pointer that was read from memory is "generic" to the compiler: loads and stores through it would be FLAT instructions.
 // Every pointer in the argument structs is a device-memory address: say so (a round trip through the global address space,
 // from which the compiler's address-space inference takes it).
