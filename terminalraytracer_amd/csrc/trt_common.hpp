@@ -21,8 +21,8 @@ constexpr int kPersistentBlock = TRT_BLOCK;
 #define TRT_STAMP 0
 #endif
 #if TRT_STAMP == 2
-// -DTRT_STAMP=2: the "clock" is s101, which tools/count_isa.py makes a count of executed instructions (it inserts an add at the
-// head of every basic block of the compiler's assembly: tools/build_isa_count.sh); the per-stage sums are then instruction counts
+// -DTRT_STAMP=2: the "clock" is s101, which tools/archive/count_isa.py makes a count of executed instructions (it inserts an add at the
+// head of every basic block of the compiler's assembly: tools/archive/build_isa_count.sh); the per-stage sums are then instruction counts
 #define TRT_STAMP_AT(slot)                                                  \
     do                                                                      \
     {                                                                       \
@@ -58,7 +58,7 @@ constexpr int kPersistentBlock = TRT_BLOCK;
         __builtin_amdgcn_sched_barrier(0);                       \
     } while (0)
 #elif defined(TRT_MARKS)
-// -DTRT_MARKS=1: the stage boundaries as comments in the compiler's assembly (tools/isa_stage_counts.py counts the
+// -DTRT_MARKS=1: the stage boundaries as comments in the compiler's assembly (tools/archive/isa_stage_counts.py counts the
 // instructions between them); a scheduling barrier keeps each stage's instructions on its own side
 #define TRT_STAMP_AT(slot)                      \
     do                                          \

@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__((COMPACT || BIG) ? kCompactBlock : kPersistentBlock
 
     TRT_STAGE_STAMPS(tally);
 #if TRT_STAMP == 2
-    stamp_prev = 0; // the instruction count starts at 0 at the kernel's entry (tools/count_isa.py); the prologue goes to the first slot
+    stamp_prev = 0; // the instruction count starts at 0 at the kernel's entry (tools/archive/count_isa.py); the prologue goes to the first slot
 #elif TRT_STAMP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B the production kernel across alternative builds of libtrt_hip.so in ONE process-per-variant loop on one GPU box.
-# usage: tools/ab_bench.sh <rounds> <lib> [<lib> ...]     (interleaved rounds; prints ms/frame per round)
+# usage: tools/archive/ab_bench.sh <rounds> <lib> [<lib> ...]     (interleaved rounds; prints ms/frame per round)
 rounds=$1; shift
 for r in $(seq $rounds); do
   for lib in "$@"; do

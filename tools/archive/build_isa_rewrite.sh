@@ -1,7 +1,7 @@
 #!/bin/bash
-# libtrt_hip.so with the render unit's device assembly passed through tools/rewrite_isa.py: hipcc -S (device) -> rewrite -> assemble ->
+# libtrt_hip.so with the render unit's device assembly passed through tools/archive/rewrite_isa.py: hipcc -S (device) -> rewrite -> assemble ->
 # link -> bundle -> host compile with the bundle embedded -> shared library with the library's other units.
-# usage: tools/build_isa_rewrite.sh <out.so> [extra -D flags]
+# usage: tools/archive/build_isa_rewrite.sh <out.so> [extra -D flags]
 set -e
 OUT=${1:-build/e64.so}; shift || true
 LLVM=/opt/rocm/lib/llvm/bin
@@ -12,7 +12,7 @@ FLAGS="$TUNE --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp
 T=build/isa_$(basename $OUT .so); mkdir -p $T
 make -s -j6 lib LIB=$T/plain.so TUNE="$TUNE" > /dev/null
 /opt/rocm/bin/hipcc $FLAGS --cuda-device-only -S -o $T/dev.s $CSRC/trt_render.hip
-python3 tools/rewrite_isa.py $T/dev.s $T/dev2.s
+python3 tools/archive/rewrite_isa.py $T/dev.s $T/dev2.s
 $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c $T/dev2.s -o $T/dev.o
 $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $T/dev.out $T/dev.o
 $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 -input=/dev/null -input=$T/dev.out -output=$T/dev.hipfb

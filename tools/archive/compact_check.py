@@ -1,6 +1,6 @@
 """A/B of the shading compaction (trt_set_compaction): frames with it on must equal frames with it off, bit for bit; time both."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import support as T

@@ -7,7 +7,7 @@ stamps of the diagnostic build (TRT_STAMP_AT) then read s101 instead of the cloc
 TRT_PRINT_STAMPS prints are wave-level instruction counts per stage.  The kernels must leave s100 / s101 alone
 (.amdhsa_next_free_sgpr <= 100: checked), and the pass raises it to 102.
 
-usage: python tools/count_isa.py in.s out.s <kind>     kind: valu | fp64 | trans | salu | lds | vmem | cndmask | all"""
+usage: python tools/archive/count_isa.py in.s out.s <kind>     kind: valu | fp64 | trans | salu | lds | vmem | cndmask | all"""
 import re
 import sys
 

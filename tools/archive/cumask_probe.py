@@ -1,10 +1,10 @@
 """Throughput of the bench frame against the number of compute units a CU-masked stream leaves out (trt_reserve_cus).
-Run on the GPU box: python tools/cumask_probe.py"""
+Run on the GPU box: python tools/archive/cumask_probe.py"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

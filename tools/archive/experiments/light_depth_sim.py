@@ -1,5 +1,5 @@
 """EXPERIMENT (round 4): light tables with a depth coordinate, any-hit search for point lights -- host simulation on the oracle's
-shadow rays (tools/experiments/light_depth_sim.c).  Usage: python tools/experiments/light_depth_sim.py [spheres]"""
+shadow rays (tools/archive/experiments/light_depth_sim.c).  Usage: python tools/archive/experiments/light_depth_sim.py [spheres]"""
 import ctypes as C
 import os
 import subprocess
@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import support as T  # noqa: E402
@@ -26,7 +26,7 @@ def main():
     so = "/tmp/liblightdepthsim.so"
     inc = os.path.join(ROOT, "terminalraytracer_amd", "csrc")
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-I" + inc, "-o", so,
-                           os.path.join(ROOT, "tools", "experiments", "light_depth_sim.c"), "-lm"])
+                           os.path.join(ROOT, "tools", "archive", "experiments", "light_depth_sim.c"), "-lm"])
     lib = C.CDLL(so)
     lib.depth_sim.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(DepthStats)]
     lib.depth_sim.restype = None

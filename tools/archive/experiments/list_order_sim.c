@@ -4,7 +4,7 @@
  * the list is ordered by L_j = |c_j - A| - r_j and a lane stops as soon as its best hit is nearer than anything the rest of
  * the list could offer (t_best < L_j - |o - A|), with the ground tested first.  Also the per-64-ray maxima (a wave runs as
  * long as its busiest lane).  Not product code. */
-#include "../../tests/raygrid_check.c"
+#include "../../../tests/raygrid_check.c"
 
 typedef struct
 {

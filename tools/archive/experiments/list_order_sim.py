@@ -1,5 +1,5 @@
 """EXPERIMENT (round 4): candidate lists ordered by distance from the family's apex, lanes stopping early -- a host simulation on
-the oracle's path rays (tools/experiments/list_order_sim.c).  Usage: python tools/experiments/list_order_sim.py [spheres] [g_sph] [m]"""
+the oracle's path rays (tools/archive/experiments/list_order_sim.c).  Usage: python tools/archive/experiments/list_order_sim.py [spheres] [g_sph] [m]"""
 import ctypes as C
 import os
 import subprocess
@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import support as T  # noqa: E402
@@ -28,7 +28,7 @@ def main():
     so = "/tmp/liblistordersim.so"
     inc = os.path.join(ROOT, "terminalraytracer_amd", "csrc")
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-I" + inc, "-o", so,
-                           os.path.join(ROOT, "tools", "experiments", "list_order_sim.c"), "-lm"])
+                           os.path.join(ROOT, "tools", "archive", "experiments", "list_order_sim.c"), "-lm"])
     lib = C.CDLL(so)
     lib.order_sim.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                               C.c_double, C.c_int, C.POINTER(OrderStats)]

@@ -1,7 +1,7 @@
 // sweep_mfma_archive.hpp -- the two matrix-core forms of the FP32 culling sweep that were measured and REJECTED in round 1
 // (DESIGN.md 4.8): 32x32x2 tiles for every sweep (166 VGPRs, 3 waves/SIMD: 3.34 ms against 3.30 ms on the VALU) and
 // 16x16x4 tiles for the path rays only (131 VGPRs: 2.51 ms against 2.24 ms).  Kept for the record together with the
-// probes that established the rounding model of the instructions (tools/mfma_probe.hip, tools/mfma16_probe.hip).
+// probes that established the rounding model of the instructions (tools/archive/mfma_probe.hip, tools/archive/mfma16_probe.hip).
 // NOT part of the library any more and not compiled by the build: these functions used the LdsImage fields a_xy / a_zk /
 // a_zk_dir / mfma16_wave of the round-1 kernel (see git history of csrc/trt_rounds.hpp at 5726ee7 for the call sites).
 #pragma once

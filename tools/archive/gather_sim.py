@@ -2,7 +2,7 @@
 the same slot/event structure as HipShardRenderer; the gather is stood in for by a busy-wait kernel of fixed length on the
 main stream (a gather occupies the stream, not the CUs).  Prints ms per frame for several numbers of frames in flight."""
 import os, sys, time, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from terminalraytracer_amd import hip

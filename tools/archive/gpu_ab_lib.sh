@@ -1,4 +1,4 @@
-# usage: bash tools/gpu_ab_lib.sh build/a.so build/b.so ...   (the shipped library is always the first contestant)
+# usage: bash tools/archive/gpu_ab_lib.sh build/a.so build/b.so ...   (the shipped library is always the first contestant)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for r in 1 2; do

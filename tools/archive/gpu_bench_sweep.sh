@@ -1,6 +1,6 @@
 #!/bin/bash
 # bench.py over one setting at a time on the GPU box, config 3 and config 5 (--animation 60), a line per run.
-# usage: gpurun -- bash tools/gpu_bench_sweep.sh <what> <value> [<value> ...]
+# usage: gpurun -- bash tools/archive/gpu_bench_sweep.sh <what> <value> [<value> ...]
 #   what = depth     frames in flight (--depth)                       e.g. depth 1 2 3 4
 #          pathgrid  TRT_PATHGRID="eye,sphere[,patches]"              e.g. pathgrid 64,32 64,48 64,32,2
 #          lightgrid TRT_LIGHTGRID="directional,point"                e.g. lightgrid 128,64 256,64

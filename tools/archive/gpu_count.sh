@@ -1,14 +1,14 @@
 #!/bin/bash
-# Executed instructions per stage and round of the plain rounds (build/count_<kind>.so from tools/build_isa_count.sh), config 3 and 5
-# usage: gpurun -- bash tools/gpu_count.sh [kind ...]     -> gpurun_out/counts/<config>_<kind>.txt and a table
+# Executed instructions per stage and round of the plain rounds (build/count_<kind>.so from tools/archive/build_isa_count.sh), config 3 and 5
+# usage: gpurun -- bash tools/archive/gpu_count.sh [kind ...]     -> gpurun_out/counts/<config>_<kind>.txt and a table
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/counts; mkdir -p $out
 export TRT_COMPACTION=0
 kinds="${@:-valu fp64 trans cmp cndmask mov salu wait lds vmem}"
 for k in $kinds; do
-  TRT_HIP_LIB=$PWD/build/count_$k.so timeout -k 10 120 python3 tools/stamp_config.py 1920 1080 64 8 > $out/c3_$k.txt 2>&1 || { tail -5 $out/c3_$k.txt; exit 1; }
-  TRT_HIP_LIB=$PWD/build/count_$k.so timeout -k 10 120 python3 tools/stamp_config.py 1920 1080 256 12 > $out/c5_$k.txt 2>&1 || { tail -5 $out/c5_$k.txt; exit 1; }
+  TRT_HIP_LIB=$PWD/build/count_$k.so timeout -k 10 120 python3 tools/archive/stamp_config.py 1920 1080 64 8 > $out/c3_$k.txt 2>&1 || { tail -5 $out/c3_$k.txt; exit 1; }
+  TRT_HIP_LIB=$PWD/build/count_$k.so timeout -k 10 120 python3 tools/archive/stamp_config.py 1920 1080 256 12 > $out/c5_$k.txt 2>&1 || { tail -5 $out/c5_$k.txt; exit 1; }
 done
 python3 - $out $kinds <<'PY'
 import re, sys

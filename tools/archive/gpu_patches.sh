@@ -1,7 +1,7 @@
 #!/bin/bash
 # Sub-families of the spheres (trt_raygrid.h patches): parity tests of the tables, then config 5 / config 3 with the tables'
 # resolution and the number of patches from the environment (TRT_PATHGRID="eye,sphere,m").  Output under gpurun_out/patches/.
-# usage: gpurun -- bash tools/gpu_patches.sh [tests|notests]
+# usage: gpurun -- bash tools/archive/gpu_patches.sh [tests|notests]
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/patches; mkdir -p $out

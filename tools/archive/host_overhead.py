@@ -1,7 +1,7 @@
 """CPU-side cost per frame of the multi-GPU loop (HipShardRenderer.render: launches, events, one gather, one index_select),
 measured on one GPU with a 1-rank RCCL group and a frame so small that the GPU is never the limit."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 import torch, torch.distributed as dist
 import bench

@@ -1,6 +1,6 @@
 """Static instruction counts per stage of a render kernel, from the compiler's assembly of a -DTRT_MARKS=1 build
 (hipcc --save-temps): the stage boundaries are `; MARK <slot>` comments.  Instructions are attributed to the mark that
-precedes them in layout order; loop bodies count once.  usage: python tools/isa_stage_counts.py <file.s> <mangled-kernel-substring>"""
+precedes them in layout order; loop bodies count once.  usage: python tools/archive/isa_stage_counts.py <file.s> <mangled-kernel-substring>"""
 import collections, re, sys
 path, want = sys.argv[1], sys.argv[2]
 lines = open(path).read().split("\n")

@@ -1,5 +1,5 @@
 // mfma16_probe.hip -- operand / result layout and rounding model of v_mfma_f32_16x16x4_f32 on gfx950.
-//   hipcc --offload-arch=gfx950 -O2 -o /tmp/mfma16_probe tools/mfma16_probe.hip && /tmp/mfma16_probe
+//   hipcc --offload-arch=gfx950 -O2 -o /tmp/mfma16_probe tools/archive/mfma16_probe.hip && /tmp/mfma16_probe
 // D[i][j] = sum_k A[i][k] * B[k][j] + C[i][j], i, j < 16, k < 4.  Expected layout (CDNA3 ISA):
 //   A: lane l holds A[i = l%16][k = l/16];  B: lane l holds B[k = l/16][j = l%16];  C/D: lane l, register v holds [i = 4*(l/16) + v][j = l%16]
 #include <hip/hip_runtime.h>

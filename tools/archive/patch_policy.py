@@ -1,8 +1,8 @@
 """When do the spheres' patches pay?  Render kernel time (one frame at a time, HIP events) of SYNTH-v0 scenes of n spheres at
 1920x1080, 12 bounces, with one family per sphere (m = 0; the shading decoupled where the rings fit, as the library would) and with
-24 patches (m = 2).  usage (GPU box): python tools/patch_policy.py [n ...]"""
+24 patches (m = 2).  usage (GPU box): python tools/archive/patch_policy.py [n ...]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from terminalraytracer_amd import hip, scenes as S

@@ -1,6 +1,6 @@
 """Stage shares (s_memtime stamps, -DTRT_STAMP=1 build selected through TRT_HIP_LIB) for an arbitrary config."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["TRT_PRINT_STAMPS"] = "1"
 from terminalraytracer_amd import hip, scenes as S
 w, h, n, b = (int(x) for x in sys.argv[1:5])

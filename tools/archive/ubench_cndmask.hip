@@ -2,7 +2,7 @@
 // ubench_valu.hip found v_cndmask_b32 with VCC at 15.5 cycles per wave instruction against 2.9 with an SGPR pair.  Here:
 //   e32 vcc | e64 vcc | e64 s[20:21] | a compare into vcc followed by two selects on it (a 64-bit select, the kernel's pattern),
 //   e32 and e64 | the same with the compare writing s[20:21].
-// Build: hipcc --offload-arch=gfx950 -O2 -o tools/ubench_cndmask tools/ubench_cndmask.hip ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O2 -o tools/ubench_cndmask tools/archive/ubench_cndmask.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

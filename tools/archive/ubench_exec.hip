@@ -1,7 +1,7 @@
 // ubench_exec.hip -- does gfx950 skip the passes of a wave64 VALU instruction whose lanes are all switched off?
 // The same loop of independent v_fma_f64 / v_mul_f64 / v_cndmask_b32 / v_fma_f32 runs under exec masks with 64, 32 (lower
 // half), 16, 1 and 4-scattered (one lane per 16-lane group) active lanes; s_memtime around the loop, 1 / 2 / 4 waves per SIMD.
-// Build: hipcc --offload-arch=gfx950 -O2 -o tools/ubench_exec tools/ubench_exec.hip ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O2 -o tools/ubench_exec tools/archive/ubench_exec.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

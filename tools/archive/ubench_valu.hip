@@ -1,7 +1,7 @@
 // ubench_valu.hip -- issue cost of the VALU instructions the frame producer is made of, on gfx950.
 // Each kernel runs ITER x 32 copies of one instruction on 8 independent register sets and stamps
 // s_memtime around the loop; cycles per wave-instruction are reported at 1, 2 and 4 waves per SIMD.
-// Build: hipcc --offload-arch=gfx950 -O2 -o /tmp/ubench tools/ubench_valu.hip ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O2 -o /tmp/ubench tools/archive/ubench_valu.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

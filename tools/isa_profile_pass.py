@@ -10,7 +10,7 @@ that kind the wave EXECUTED in the intervals that START at boundary `slot` (lane
 counts the boundaries themselves (visits: boundary 0 is passed once per round).  The kernel's epilogue adds the eleven
 registers to counters[40 ...] (csrc/trt_rounds.hpp), `TRT_PRINT_PROFILE=1` prints them (trt_read_counters).
 
-Unlike tools/count_isa.py (stamp sums in 48 SGPRs, which the diagnostic build spills to VGPR lanes: ~140 extra moves per
+Unlike tools/archive/count_isa.py (stamp sums in 48 SGPRs, which the diagnostic build spills to VGPR lanes: ~140 extra moves per
 round, and the COUNTING instantiation), the code profiled here is the shipping instantiation's own register allocation and
 instruction selection; only the scheduling barriers at the boundaries differ.  One library, one run, every kind.
 
