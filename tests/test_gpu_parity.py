@@ -393,6 +393,28 @@ def test_c_abi_dist_renderer_world_of_one(ctx, through_rccl):
         hip.Dist(0, scene, None, 0, 2, 128, 72)  # more than one rank needs the communicator's id
 
 
+def test_dist_renderer_on_a_scene_of_more_than_256_spheres(ctx):
+    """The frame slots of a trt_dist share ONE copy of the scene's tables and keep the eye's two tables in slots of their own -- here
+    with everything round 5 added for large scenes: 16-bit list entries, the wide family builder, eye parts of the pool sized for the
+    longest lists, the plain rounds in 1024-thread workgroups.  Cameras in turn over three slots (every slot's eye tables rebuilt),
+    then a new scene of another size on the same renderer: every frame the oracle's."""
+    scene = S.synth_scene(320, T.sky("synth"), T.bench_camera(96, 54, 2.5), seed=21)
+    with hip.Dist(0, scene, None, 0, 1, 96, 54, tile_rows=8, frames_in_flight=3) as d:
+        cams = [T.bench_camera(96, 54, t) for t in (0.0, 0.5, 1.0, 2.5, 10.0, 33.3, 0.5)]
+        frames = [d.fetch(d.render(cam, 6, 3)) for cam in cams]
+        for cam, got in zip(cams, frames):
+            want, _ = T.oracle_render(scene.with_camera(cam), 96, 54, 6, 3)
+            assert np.array_equal(bits(got), bits(want))
+        assert d.context(0).render_variant()["workgroup_threads"] == 1024 and d.context(0).scene_info()["sharers"] == 3
+        smaller = S.synth_scene(200, T.sky("synth"), T.bench_camera(96, 54, 1.0), seed=22)
+        d.set_scene(smaller)
+        for t in (1.0, 10.0, 2.5, 0.0):
+            cam = T.bench_camera(96, 54, t)
+            want, _ = T.oracle_render(smaller.with_camera(cam), 96, 54, 6, 3)
+            assert np.array_equal(bits(d.fetch(d.render(cam, 6, 3))), bits(want)), t
+        assert d.context(1).render_variant()["workgroup_threads"] == 256
+
+
 def test_c_host_drives_the_dist_renderer(tmp_path):
     """examples/trt_dist_demo: a C host, one process per GPU, the communicator id carried through a file -- here one rank, so
     communicator, group and assembly all run on the one GPU.  Its last frame must be the frame the single-GPU C demo's
