@@ -1003,6 +1003,7 @@ __global__ __launch_bounds__((COMPACT || BIG) ? kCompactBlock : kPersistentBlock
     const int lane = threadIdx.x & 63;
     const unsigned pixels_here = (unsigned)f.local_rows * (unsigned)f.width;
     const unsigned total = pixels_here * (unsigned)f.spp; // work units, < 2^31
+    (void)total; // TRT_FRESH_ARGS re-derives it where it is used
     const d3 gp = load3(s.ground), gn = load3(s.ground + 3);
 
     // ---- per-lane state ------------------------------------------------------------------------------
