@@ -454,7 +454,6 @@ int ensure_eye_tables(trt_context *ctx, const Camera *camera, hipStream_t stream
         return TRT_OK;
     trt_eye_families(eye, ctx->T->ground_built, &ctx->T->cull_scene, g.eye);
     const int n = (int)(ctx->T->h_spheres.size() / 9), ge = g.g_eye;
-    const size_t eye_cells = 6 * (size_t)ge * ge;
     // this context's part of the pool: behind the scene's part and the parts of the slots before it
     const size_t pool_from = ctx->T->pool_scene_words + (size_t)ctx->eye_slot * ctx->T->pool_eye_words;
     unsigned long long *const counter = ctx->T->d_pool_used.ptr + 16 * (1 + ctx->eye_slot);
