@@ -482,7 +482,7 @@ extern "C" int trt_render_variant(trt_context *ctx, int *decoupled, int *workgro
     if (decoupled)
         *decoupled = d ? 1 : 0;
     if (workgroup_threads)
-        *workgroup_threads = ctx->kernel == 1 ? 256 : (d || (ctx->last_units > 0 ? ctx->last_big : renders_big(ctx)) ? trt::kCompactBlock : trt::kPersistentBlock);
+        *workgroup_threads = ctx->kernel == 1 ? 256 : (d ? trt::kCompactBlock : (ctx->last_units > 0 ? ctx->last_big : renders_big(ctx)) ? trt::kBigBlock : trt::kPersistentBlock);
     return TRT_OK;
 }
 

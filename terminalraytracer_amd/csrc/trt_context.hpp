@@ -319,7 +319,7 @@ inline bool print_host_times()
 inline bool renders_big(const trt_context *ctx)
 {
     return ctx->kernel == 0 && !ctx->ior_count && !ctx->counters_enabled && ctx->grids.path_enabled && ctx->grids.patch_m > 0 &&
-           ctx->big_blocks_per_cu * trt::kCompactBlock > ctx->rounds_blocks_per_cu * trt::kPersistentBlock;
+           ctx->big_blocks_per_cu * trt::kBigBlock > ctx->rounds_blocks_per_cu * trt::kPersistentBlock;
 }
 
 inline bool rowset_valid(const trt_rowset *r)

@@ -3,6 +3,9 @@
 // Compiled for gfx950 only, with -ffp-contract=off (see trt_device.hpp).
 #define TRT_UNIT_RENDER 1 // this unit is the home of the kernels that are not templates (trt_common.hpp, trt_simple.hpp)
 #include "trt_context.hpp"
+#ifndef TRT_REDUCE_BLOCK
+#define TRT_REDUCE_BLOCK 64 // one wave: fits beside the render kernels of the frames in flight wherever a wave retires (+0.8 % decoupled)
+#endif
 #include "trt_simple.hpp"
 
 using namespace trt_impl;
@@ -34,7 +37,7 @@ int refresh_occupancy(trt_context *ctx)
         ctx->big_blocks_per_cu = 0;
         if (ctx->rounds_blocks_per_cu < 4) // the image no longer fits four times: one image for sixteen waves instead
         {
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false, false, false, true, true>, trt::kCompactBlock,
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, trt::render_rounds_kernel<false, false, false, true, true>, trt::kBigBlock,
                                                                  image_lds_bytes(ctx, 64)));
             ctx->big_blocks_per_cu = blocks;
         }
@@ -235,7 +238,9 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
     }
     else
     {
+#if !TRT_OPT_FIRSTCHUNK
         HIP_TRY(hipMemsetAsync(ctx->d_queue.ptr + 16 * lane_set, 0, 16 * sizeof(unsigned int), stream));
+#endif
         // production (kernel 0): persistent waves, synchronous rounds over SAMPLE units, then the ordered mean per pixel
         const long units = pixels * rays_per_pixel;
         if ((unsigned long long)units >= 0x7fffffffull)
@@ -265,8 +270,8 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         if (big)
         {
             const long cap = (long)(ctx->compute_units - (ctx->stream == ctx->own_stream ? ctx->reserved_cus : 0)) * ctx->big_blocks_per_cu;
-            const long want = (units + trt::kCompactBlock - 1) / trt::kCompactBlock;
-            pl = trt::PersistentLaunch{(unsigned)std::max(1L, std::min(want, cap)), (unsigned)trt::kCompactBlock};
+            const long want = (units + trt::kBigBlock - 1) / trt::kBigBlock;
+            pl = trt::PersistentLaunch{(unsigned)std::max(1L, std::min(want, cap)), (unsigned)trt::kBigBlock};
         }
         ctx->last_big = big;
         const size_t plds = image_lds_bytes(ctx, rays_per_pixel);
@@ -274,6 +279,10 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         if (ctx->ior_count && ctx->ior_count != ctx->scene.num_spheres) // before the first event of the launch is recorded
             return fail(TRT_ERR_ARGUMENT, "trt_set_refraction was given %d indices, the scene has %d spheres", ctx->ior_count, ctx->scene.num_spheres);
         ctx->last_compact = compact;
+#if TRT_OPT_FIRSTCHUNK
+        // every wave owns its first chunk of units without asking (wave w: chunk w); the queue starts behind those
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->d_queue.ptr + 16 * lane_set), (int)(pl.grid * (pl.block / 64) * trt::kQueueChunkSamples), 16, stream));
+#endif
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
         const bool patches = ctx->grids.path_enabled && ctx->grids.patch_m > 0; // a family per patch of a sphere: its own instantiations
         if (ctx->ior_count)
@@ -311,7 +320,7 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
 #if !TRT_AB_SKIP_REDUCE // diagnostic build (profiles/r03: what the ordered mean's streaming pass costs in the pipelined loop)
         { // TRT.c:1063-1065: the mean over each pixel's samples, in sample order
             const long values = pixels * 3;
-            hipLaunchKernelGGL(trt::reduce_samples_kernel, dim3((unsigned)((values + 255) / 256)), dim3(256), 0, stream,
+            hipLaunchKernelGGL(trt::reduce_samples_kernel, dim3((unsigned)((values + TRT_REDUCE_BLOCK - 1) / TRT_REDUCE_BLOCK)), dim3(TRT_REDUCE_BLOCK), 0, stream,
                                (const double *)scratch.ptr, (double *)d_pixels, values, rays_per_pixel, f.inv_spp);
         }
 #endif

@@ -45,6 +45,9 @@
 #ifndef TRT_OPT_POOLCHECK
 #define TRT_OPT_POOLCHECK 1 // the exact loops ask the lanes for a pool word only in the iterations that can need one
 #endif
+#ifndef TRT_OPT_FIRSTCHUNK
+#define TRT_OPT_FIRSTCHUNK 1 // a wave's first chunk of units is its own: no 4096 atomics on one word at the start of a frame (+1.5 %)
+#endif
 #ifndef TRT_OPT_EXPECT
 #define TRT_OPT_EXPECT 1 // the whole-wave sweep and the closest-hit search of a point light are the rare ways: laid out as such
 #endif
@@ -907,7 +910,7 @@ TRT_DEV d3 shadow_stage(const LdsImage &L, const CullView &cull, const GridView 
 // (TRT.c:1040 adds them in that order; the sky colour of TRT.c:1044 after them).  What is computed for a task is what the
 // owner would have computed, operation for operation; only WHICH lane computes it, and when, changes.
 constexpr int kRingTasks = 128;                            // >= 63 carried over + 64 new
-constexpr int kRingDoubles = 7 * kRingTasks + kRingTasks / 2 + 3 * 64; // point(3) normal(3) weight(1) as arrays of doubles, material as ints;
+constexpr int kRingDoubles = 7 * kRingTasks + kRingTasks / 4 + 3 * 64; // point(3) normal(3) weight(1) as arrays of doubles, material as 16-bit ints;
                                                                         // then per LANE the direction of its next path ray while the wave shades
 
 // The kernel's arguments live in the kernarg segment (constant address space, read with scalar loads).  Held in SGPRs for the
@@ -979,11 +982,11 @@ TRT_DEV GridView in_device_memory(GridView v)
     const d3 gp = load3(s.ground), gn = load3(s.ground + 3);                                       \
     (void)n, (void)nd, (void)nl, (void)total, (void)pixels_here, (void)gp, (void)gn, (void)cull, (void)grids
 
-#ifdef TRT_NATURAL
-constexpr int kCompactBlock = 256;
-#else
-constexpr int kCompactBlock = 1024;
-#endif // one workgroup per CU: 16 rings and one image share the CU's 160 KB of LDS
+#ifndef TRT_COMPACT_BLOCK
+#define TRT_COMPACT_BLOCK 1024 // one workgroup per CU: 16 rings and one image share the CU's 160 KB of LDS
+#endif
+constexpr int kCompactBlock = TRT_COMPACT_BLOCK;
+constexpr int kBigBlock = 1024;
 
 // PATCHES: the path rays' tables have a family per PATCH of a sphere's surface (GridView::patch_m > 0, trt_raygrid.h) instead of
 // one per sphere: another look-up (path_cell_patches), the same everything else.  Its own instantiation, so that scenes
@@ -992,7 +995,7 @@ constexpr int kCompactBlock = 1024;
 // image no longer fits four times into a CU's 160 KB (above ~290 spheres: 136 bytes a sphere): with 256-thread workgroups such a
 // scene runs three, two, one wave per SIMD (512 spheres: two).  Same code; the register allocator has to stay under 128.
 template <bool COUNT, bool REFRACT = false, bool COMPACT = false, bool PATCHES = false, bool BIG = false>
-__global__ __launch_bounds__((COMPACT || BIG) ? kCompactBlock : kPersistentBlock, (((COMPACT && !COUNT) || BIG) && kCompactBlock == 1024) ? 4 : TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
+__global__ __launch_bounds__(BIG ? kBigBlock : COMPACT ? kCompactBlock : kPersistentBlock, ((COMPACT && !COUNT) || BIG) ? 4 : TRT_ROUNDS_WAVES) void render_rounds_kernel(SceneView s, CullView cull, FrameView f, GridView grids)
 {
     static_assert(!(REFRACT && COMPACT), "the refraction extension runs on the plain rounds");
     static_assert(!(PATCHES && COMPACT), "scenes with patches run the plain rounds");
@@ -1019,10 +1022,16 @@ __global__ __launch_bounds__((COMPACT || BIG) ? kCompactBlock : kPersistentBlock
     int inside = -1;                                  // REFRACT: the refractor the pending ray travels inside of
     Tally tally;
     unsigned pool_next = 0, pool_end = 0; // wave-uniform: units fetched from the queue, not yet handed out
+#if TRT_OPT_FIRSTCHUNK
+    // the first chunk is the wave's own (the host starts the queue behind these): 4096 waves asking one address for their first
+    // units at the same moment wait in line for it
+    pool_next = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))) * kQueueChunkSamples;
+    pool_end = pool_next + kQueueChunkSamples;
+#endif
     // COMPACT: the wave's ring of shading tasks and what this lane still expects from it
     double *const ring = lds + f.ring_at + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kRingDoubles; // wave-uniform: a scalar
-    int *const ring_mat = (int *)(ring + 7 * kRingTasks);
-    double *const parked = ring + 7 * kRingTasks + kRingTasks / 2;
+    unsigned short *const ring_mat = (unsigned short *)(ring + 7 * kRingTasks); // < 2^16 materials: the LDS image ends long before
+    double *const parked = ring + 7 * kRingTasks + kRingTasks / 4;
     if (COMPACT)
     {
         for (int i = lane; i < kRingDoubles; i += 64)
@@ -1152,7 +1161,7 @@ __global__ __launch_bounds__((COMPACT || BIG) ? kCompactBlock : kPersistentBlock
                     ring[0 * kRingTasks + at] = so.x, ring[1 * kRingTasks + at] = so.y, ring[2 * kRingTasks + at] = so.z;
                     ring[3 * kRingTasks + at] = hit.normal.x, ring[4 * kRingTasks + at] = hit.normal.y, ring[5 * kRingTasks + at] = hit.normal.z;
                     ring[6 * kRingTasks + at] = weight;
-                    ring_mat[at] = hit.mat;
+                    ring_mat[at] = (unsigned short)hit.mat;
                     const d3 nd3 = reflect(d, hit.normal); // TRT.c:1054; kept in LDS while the wave shades
                     parked[lane] = nd3.x, parked[64 + lane] = nd3.y, parked[128 + lane] = nd3.z;
                     weight *= L.mat[hit.mat * 5 + 3];
