@@ -1,6 +1,7 @@
 #!/bin/bash
 # ISA profile of the shipping kernels on the GPU box (build/isa_profile.so from tools/build_isa_profile.sh): config 3 plain and
-# decoupled, config 5.   usage: gpurun -- bash tools/gpu_profile.sh [lib]      -> gpurun_out/isa_profile/*.txt
+# decoupled (a 251-register profile build fits no 1024-thread workgroup: build with `tools/build_isa_profile.sh -DTRT_COMPACT_BLOCK=256` for that
+# one), config 5.   usage: gpurun -- bash tools/gpu_profile.sh [lib]      -> gpurun_out/isa_profile/*.txt
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 lib=${1:-build/isa_profile.so}
