@@ -55,8 +55,21 @@ int trt_read_ppm(const char *filename, Color **colors, int *width, int *height)
     if (status == TRT_HOST_OK)
     {
         const size_t count = (size_t)*width * (size_t)*height;
-        Color *texels = (Color *)malloc(sizeof(Color) * count);
-        if (!texels)
+        /* a header that promises more texels than the file holds is refused before anything of that size is allocated
+         * (a seekable file knows its length; a pipe is read until it ends) */
+        int short_file = 0;
+        const long at = ftell(fp);
+        if (at >= 0 && fseek(fp, 0, SEEK_END) == 0)
+        {
+            const long end = ftell(fp);
+            short_file = end >= at && (unsigned long long)(end - at) < (unsigned long long)count * sizeof(Color);
+            if (fseek(fp, at, SEEK_SET) != 0)
+                short_file = 1;
+        }
+        Color *texels = short_file ? NULL : (Color *)malloc(sizeof(Color) * count);
+        if (short_file)
+            status = TRT_HOST_ERR_TRUNCATED;
+        else if (!texels)
             status = TRT_HOST_ERR_MEMORY;
         else if (fread(texels, sizeof(Color), count, fp) != count) /* Color is 3 packed bytes r,g,b */
         {

@@ -16,6 +16,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 FACES = ["+X", "-X", "+Y", "-Y", "+Z", "-Z"]
 
 
+# TRT_TEST_SANITIZE=1 (set by tests/test_sanitized.py for a child run): the host builds of the table headers (filter / light-table /
+# ray-table checkers) are compiled with the address and undefined-behaviour sanitizers, under another name
+SANITIZE = os.environ.get("TRT_TEST_SANITIZE") == "1"
+CHECKER_FLAGS = ["-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] if SANITIZE else []
+
+
+def checker_so(name):
+    build = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    return os.path.join(build, name + ("_san" if SANITIZE else "") + ".so")
+
+
 class OracleStats(C.Structure):
     _fields_ = [("path_rays", C.c_ulonglong), ("shadow_rays", C.c_ulonglong), ("sky_lookups", C.c_ulonglong),
                 ("samples", C.c_ulonglong)]
@@ -24,7 +36,7 @@ class OracleStats(C.Structure):
 @functools.lru_cache(maxsize=None)
 def oracle():
     """oracle/libtrt_oracle.so -- the CPU restatement.  Checker only; never on a product path."""
-    path = os.path.join(ROOT, "oracle", "libtrt_oracle.so")
+    path = os.environ.get("TRT_ORACLE_LIB") or os.path.join(ROOT, "oracle", "libtrt_oracle.so") # the variable: a sanitized build (test_oracle_golden.py)
     if not os.path.exists(path):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
     lib = C.CDLL(path)

@@ -27,14 +27,12 @@ class RayLog(C.Structure):
 
 @pytest.fixture(scope="module")
 def checker():
-    build = os.path.join(T.ROOT, "tests", "_build")
-    os.makedirs(build, exist_ok=True)
-    so = os.path.join(build, "libfiltercheck.so")
+    so = T.checker_so("libfiltercheck")
     src = os.path.join(T.ROOT, "tests", "filter_check.c")
     hdr = os.path.join(T.ROOT, "terminalraytracer_amd", "csrc", "trt_filter.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
-                               "-I" + os.path.dirname(hdr), "-o", so, src, "-lm"])
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared"] + T.CHECKER_FLAGS +
+                              ["-I" + os.path.dirname(hdr), "-o", so, src, "-lm"])
     lib = C.CDLL(so)
     lib.filter_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Stats)]
     lib.filter_check.restype = None

@@ -31,14 +31,12 @@ class AnyHitStats(C.Structure):
 
 @pytest.fixture(scope="module")
 def checker():
-    build = os.path.join(T.ROOT, "tests", "_build")
-    os.makedirs(build, exist_ok=True)
-    so = os.path.join(build, "liblightgridcheck.so")
+    so = T.checker_so("liblightgridcheck")
     src = os.path.join(T.ROOT, "tests", "lightgrid_check.c")
     inc = os.path.join(T.ROOT, "terminalraytracer_amd", "csrc")
     newest = max(os.path.getmtime(p) for p in (src, os.path.join(inc, "trt_lightgrid.h"), os.path.join(inc, "trt_filter.h")))
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-I" + inc, "-o", so, src, "-lm"])
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared"] + T.CHECKER_FLAGS + ["-I" + inc, "-o", so, src, "-lm"])
     lib = C.CDLL(so)
     lib.dirgrid_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(Stats)]
     lib.dirgrid_check.restype = None

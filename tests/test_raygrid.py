@@ -24,15 +24,13 @@ class Stats(C.Structure):
 
 
 def build_checker():
-    build = os.path.join(T.ROOT, "tests", "_build")
-    os.makedirs(build, exist_ok=True)
-    so = os.path.join(build, "libraygridcheck.so")
+    so = T.checker_so("libraygridcheck")
     src = os.path.join(T.ROOT, "tests", "raygrid_check.c")
     inc = os.path.join(T.ROOT, "terminalraytracer_amd", "csrc")
     newest = max(os.path.getmtime(p) for p in (src, os.path.join(inc, "trt_raygrid.h"), os.path.join(inc, "trt_lightgrid.h"),
                                                os.path.join(inc, "trt_filter.h")))
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-shared", "-I" + inc, "-o", so, src, "-lm"])
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC", "-shared"] + T.CHECKER_FLAGS + ["-I" + inc, "-o", so, src, "-lm"])
     lib = C.CDLL(so)
     lib.raygrid_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(Stats)]
