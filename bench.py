@@ -37,6 +37,9 @@ import time
 # every HIP stream of a process is dealt onto one of a few hardware queues (4 by default), and streams that share a queue
 # run one after the other: the render streams of the frames in flight, the assembly stream and RCCL's must not collide
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# this pool's host driver offers dmabuf IPC only: without it RCCL's peer buffers fail with hipIpcGetMemHandle: invalid argument
+# (exported by the image already; kept here for a launcher that builds its own environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
