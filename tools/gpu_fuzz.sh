@@ -6,7 +6,8 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/fuzz
 for job in "$@"; do
   echo "== fuzz_campaign.py $job"
-  timeout -k 10 1000 python3 tools/fuzz_campaign.py $job 2>&1 | grep -v "^\.\.\. " | tail -6
+  # the campaign's progress lines go to a file under gpurun_out/ (a run that writes nothing for seven minutes is taken to be hung)
+  timeout -k 10 1000 python3 -u tools/fuzz_campaign.py $job 2>&1 | tee -a gpurun_out/fuzz/progress.log | grep -v "^\.\.\. " | tail -6
 done | tee gpurun_out/fuzz/fuzz.txt
 grep -q MISMATCH gpurun_out/fuzz/fuzz.txt && exit 1
 exit 0
