@@ -244,9 +244,9 @@ static int init_context(trt_context *ctx)
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_band[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIP_TRY(ctx->d_counters.reserve(kCounterSlots));
-    HIP_TRY(ctx->d_queue.reserve(64));
+    HIP_TRY(ctx->d_queue.reserve(trt::kQueueWords));
     HIP_TRY(hipMemset(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(ctx->d_queue.ptr, 0, 64 * sizeof(unsigned int)));
+    HIP_TRY(hipMemset(ctx->d_queue.ptr, 0, trt::kQueueWords * sizeof(unsigned int)));
     allow_large_lds_tables(ctx);
     allow_large_lds_render(ctx);
     allow_large_lds_diag(ctx);

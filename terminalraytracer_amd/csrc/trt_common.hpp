@@ -91,6 +91,21 @@ constexpr int kProfileKinds = 11, kProfileAt = 40; // counters[kProfileAt + 64 k
 #endif
 constexpr unsigned kQueueChunkSamples = TRT_QUEUE_CHUNK;
 static_assert(kQueueChunkSamples >= 64, "a chunk must hold the 64 units the lanes of a wave can ask for in one round");
+// The queue of a launch is ONE word, or eight (FrameView::queue_shift = 3), one per XCD: the eight L2s keep a contended line coherent
+// by passing it around, so a word that only the waves of one XCD ask stays in that XCD's L2 -- a request costs a trip to L2 instead
+// of a trip through the fabric, and chunks of half the size stop costing 14 % (profiles/r05/f_ab_log.txt section 16).  Word x hands
+// out the chunks (j << shift) + x, j = 0, 1, ..., to the waves of the workgroups x, x + 8, ... -- which the dispatcher deals to the
+// XCDs in turn; were it to deal them otherwise, the frame would be the same and only the trips longer.  A wave's FIRST chunk is
+// its own: workgroup g, wave k: chunk (j << shift) + (g mod words), j = (g >> shift) * waves per workgroup + k; start_queue_kernel
+// starts every word behind those.  The words carry equal work and equal numbers of waves; nobody steals.
+constexpr int kQueueXcdShift = 3, kQueueStride = 32;              // words are a 128-byte line apart
+constexpr int kQueueLaneWords = (1 << kQueueXcdShift) * kQueueStride; // per lane set (the context's stream, the alternate one)
+constexpr int kQueueWords = 2 * kQueueLaneWords;
+#ifndef TRT_QUEUE_SMALL_DIV
+#define TRT_QUEUE_SMALL_DIV 2
+#endif
+constexpr unsigned kQueueChunkSmall = TRT_QUEUE_CHUNK / TRT_QUEUE_SMALL_DIV; // the chunk of a launch whose queue has a word per XCD
+static_assert(kQueueChunkSmall >= 64, "see kQueueChunkSamples");
 #ifndef TRT_CULL_GROUP
 #define TRT_CULL_GROUP 8
 #endif
@@ -124,6 +139,13 @@ constexpr int kDirGridDoubles = 14, kPointGridDoubles = 9;  // sizeof(trt_dirgri
 // TRT.c:1063-1066 for frames rendered with samples as work units: pixel = (((0 + s0) + s1) + ...) * (1/spp),
 // samples in index order.  The scratch is sample-major, samples[(k*pixels + pixel)*3 + channel], so that for every k
 // consecutive threads read consecutive doubles (a pure streaming kernel: spp*24 B read + 24 B written per pixel).
+// every word of a launch's queue behind the first chunks of its workgroups (see kQueueStride)
+__global__ void start_queue_kernel(unsigned int *queue, unsigned grid, unsigned waves_per_group, unsigned shift)
+{
+    const unsigned x = threadIdx.x, words = 1u << shift;
+    if (x < words)
+        queue[x * kQueueStride] = (grid > x ? (grid - x + words - 1) >> shift : 0u) * waves_per_group;
+}
 __global__ __launch_bounds__(256) void reduce_samples_kernel(const double *samples, double *out, long values, int spp, double inv_spp)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; // one thread per colour channel of a pixel

@@ -262,6 +262,8 @@ struct FrameView
     unsigned long long *counters; // [path, shadow] or nullptr
     unsigned int *queue;  // work-queue head for the persistent kernel
     unsigned ring_at;     // render_rounds_kernel<.., .., true>: where the waves' shading rings start in LDS, in doubles
+    unsigned queue_shift; // render_rounds_kernel: the queue has 1 << queue_shift words (1, or one per XCD), see kQueueStride
+    unsigned chunk;       // ... and hands out chunks of this many units
     int width, height;
     int tile_rows, tile_first, tile_step;
     int local_rows;

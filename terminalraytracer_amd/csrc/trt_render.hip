@@ -3,6 +3,9 @@
 // Compiled for gfx950 only, with -ffp-contract=off (see trt_device.hpp).
 #define TRT_UNIT_RENDER 1 // this unit is the home of the kernels that are not templates (trt_common.hpp, trt_simple.hpp)
 #include "trt_context.hpp"
+#ifndef TRT_QUEUE_PER_XCD
+#define TRT_QUEUE_PER_XCD 1
+#endif
 #ifndef TRT_REDUCE_BLOCK
 #define TRT_REDUCE_BLOCK 64 // one wave: fits beside the render kernels of the frames in flight wherever a wave retires (+0.8 % decoupled)
 #endif
@@ -209,7 +212,7 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
     f.counters = ctx->d_counters.ptr; // the ISA profile of the SHIPPING instantiations lands there
     HIP_TRY(hipMemsetAsync(ctx->d_counters.ptr, 0, kCounterSlots * sizeof(unsigned long long), lane_set ? ctx->alt_stream : ctx->stream));
 #endif
-    f.queue = ctx->d_queue.ptr + 16 * lane_set; // a cache line apart
+    f.queue = ctx->d_queue.ptr + trt::kQueueLaneWords * lane_set;
     f.width = rows->width;
     f.height = rows->height;
     f.tile_rows = rows->tile_rows;
@@ -238,9 +241,6 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
     }
     else
     {
-#if !TRT_OPT_FIRSTCHUNK
-        HIP_TRY(hipMemsetAsync(ctx->d_queue.ptr + 16 * lane_set, 0, 16 * sizeof(unsigned int), stream));
-#endif
         // production (kernel 0): persistent waves, synchronous rounds over SAMPLE units, then the ordered mean per pixel
         const long units = pixels * rays_per_pixel;
         if ((unsigned long long)units >= 0x7fffffffull)
@@ -279,10 +279,13 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         if (ctx->ior_count && ctx->ior_count != ctx->scene.num_spheres) // before the first event of the launch is recorded
             return fail(TRT_ERR_ARGUMENT, "trt_set_refraction was given %d indices, the scene has %d spheres", ctx->ior_count, ctx->scene.num_spheres);
         ctx->last_compact = compact;
-#if TRT_OPT_FIRSTCHUNK
-        // every wave owns its first chunk of units without asking (wave w: chunk w); the queue starts behind those
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ctx->d_queue.ptr + 16 * lane_set), (int)(pl.grid * (pl.block / 64) * trt::kQueueChunkSamples), 16, stream));
-#endif
+        // The queue (trt_common.hpp, kQueueStride): a word per XCD and chunks of half the size for scenes whose tables are small enough
+        // that a wave may change its place in the image twice as often (no patches), when every word has workgroups; otherwise one
+        // word.  Every wave owns its first chunk without asking.
+        const bool per_xcd = TRT_QUEUE_PER_XCD && !(ctx->grids.path_enabled && ctx->grids.patch_m > 0) && pl.grid >= (1u << trt::kQueueXcdShift);
+        f.queue_shift = per_xcd ? (unsigned)trt::kQueueXcdShift : 0u;
+        f.chunk = per_xcd ? trt::kQueueChunkSmall : trt::kQueueChunkSamples;
+        hipLaunchKernelGGL(trt::start_queue_kernel, dim3(1), dim3(64), 0, stream, f.queue, pl.grid, pl.block / 64, f.queue_shift);
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
         const bool patches = ctx->grids.path_enabled && ctx->grids.patch_m > 0; // a family per patch of a sphere: its own instantiations
         if (ctx->ior_count)

@@ -45,9 +45,6 @@
 #ifndef TRT_OPT_POOLCHECK
 #define TRT_OPT_POOLCHECK 1 // the exact loops ask the lanes for a pool word only in the iterations that can need one
 #endif
-#ifndef TRT_OPT_FIRSTCHUNK
-#define TRT_OPT_FIRSTCHUNK 1 // a wave's first chunk of units is its own: no 4096 atomics on one word at the start of a frame (+1.5 %)
-#endif
 #ifndef TRT_OPT_EXPECT
 #define TRT_OPT_EXPECT 1 // the whole-wave sweep and the closest-hit search of a point light are the rare ways: laid out as such
 #endif
@@ -1022,12 +1019,13 @@ __global__ __launch_bounds__(BIG ? kBigBlock : COMPACT ? kCompactBlock : kPersis
     int inside = -1;                                  // REFRACT: the refractor the pending ray travels inside of
     Tally tally;
     unsigned pool_next = 0, pool_end = 0; // wave-uniform: units fetched from the queue, not yet handed out
-#if TRT_OPT_FIRSTCHUNK
-    // the first chunk is the wave's own (the host starts the queue behind these): 4096 waves asking one address for their first
-    // units at the same moment wait in line for it
-    pool_next = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))) * kQueueChunkSamples;
-    pool_end = pool_next + kQueueChunkSamples;
-#endif
+    { // the queue (trt_common.hpp, kQueueStride): the first chunk is the wave's own -- 4096 waves asking for their first units at the
+      // same moment would wait in line for them
+        const unsigned group = blockIdx.x, waves = blockDim.x >> 6, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const unsigned j = (group >> f.queue_shift) * waves + wave;
+        pool_next = ((j << f.queue_shift) + (group & ((1u << f.queue_shift) - 1u))) * f.chunk;
+        pool_end = pool_next + f.chunk;
+    }
     // COMPACT: the wave's ring of shading tasks and what this lane still expects from it
     double *const ring = lds + f.ring_at + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kRingDoubles; // wave-uniform: a scalar
     unsigned short *const ring_mat = (unsigned short *)(ring + 7 * kRingTasks); // < 2^16 materials: the LDS image ends long before
@@ -1066,13 +1064,15 @@ __global__ __launch_bounds__(BIG ? kBigBlock : COMPACT ? kCompactBlock : kPersis
                     const unsigned left = pool_end - pool_next;
                     unsigned fresh = 0;
                     const int leader = __builtin_ctzll(need);
+                    const unsigned word = blockIdx.x & ((1u << f.queue_shift) - 1u); // the workgroup's word of the queue: its XCD's
                     if (lane == leader)
-                        fresh = atomicAdd(f.queue, kQueueChunkSamples);
+                        fresh = atomicAdd(f.queue + word * kQueueStride, 1u);
                     fresh = (unsigned)__builtin_amdgcn_readlane((int)fresh, leader); // the leader is wave-uniform: no cross-lane permute, no lane id
+                    fresh = ((fresh << f.queue_shift) + word) * f.chunk; // a chunk of this launch or one of the first few behind its end: < 2^32
                     if (rank >= left)
                         mine = fresh + (rank - left);
                     pool_next = fresh + (wanted - left);
-                    pool_end = fresh + kQueueChunkSamples;
+                    pool_end = fresh + f.chunk;
                 }
                 else
                     pool_next += wanted;
