@@ -146,8 +146,13 @@ __global__ void start_queue_kernel(unsigned int *queue, unsigned grid, unsigned 
     if (x < words)
         queue[x * kQueueStride] = (grid > x ? (grid - x + words - 1) >> shift : 0u) * waves_per_group;
 }
-__global__ __launch_bounds__(256) void reduce_samples_kernel(const double *samples, double *out, long values, int spp, double inv_spp)
+// ... and, being the last kernel of a frame, it leaves the frame's queue ready for a launch of the same shape (start_queue_kernel's job:
+// the next frame of this context then has no kernel in front of its render kernel)
+__global__ __launch_bounds__(256) void reduce_samples_kernel(const double *samples, double *out, long values, int spp, double inv_spp,
+                                                             unsigned int *queue, unsigned grid, unsigned waves_per_group, unsigned shift)
 {
+    if (blockIdx.x == 0 && threadIdx.x < (1u << shift)) // the render kernel that used the queue has finished
+        queue[threadIdx.x * kQueueStride] = (grid > threadIdx.x ? (grid - threadIdx.x + (1u << shift) - 1) >> shift : 0u) * waves_per_group;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; // one thread per colour channel of a pixel
     if (i >= values)
         return;

@@ -234,6 +234,9 @@ struct trt_context
     long last_units = 0;           // samples of the most recent launch (trt_render_variant / trt_kernel_info describe that launch's kernel)
     bool last_compact = false;     // the most recent launch ran the kernel with the shading decoupled
     bool last_big = false;         // ... the plain rounds in 1024-thread workgroups
+    // what the queue of each lane set was last left ready for (workgroups, waves per workgroup, words' shift; 0 workgroups: nothing):
+    // the ordered-mean pass of a frame starts the queue for the next one, which then needs no kernel of its own in front of it
+    unsigned queue_ready[2][3] = {{0, 0, 0}, {0, 0, 0}};
     int compaction = -1;           // trt_set_compaction: -1 when it costs no occupancy, 0 never, 1 whenever the rings fit
     size_t occupancy_for_lds = (size_t)-1;
     hipEvent_t ev_chunk[16]; // hand-over of framebuffer chunks to the host copy threads (trt_render_host)

@@ -285,7 +285,10 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         const bool per_xcd = TRT_QUEUE_PER_XCD && !(ctx->grids.path_enabled && ctx->grids.patch_m > 0) && pl.grid >= (1u << trt::kQueueXcdShift);
         f.queue_shift = per_xcd ? (unsigned)trt::kQueueXcdShift : 0u;
         f.chunk = per_xcd ? trt::kQueueChunkSmall : trt::kQueueChunkSamples;
-        hipLaunchKernelGGL(trt::start_queue_kernel, dim3(1), dim3(64), 0, stream, f.queue, pl.grid, pl.block / 64, f.queue_shift);
+        unsigned *const ready = ctx->queue_ready[lane_set];
+        if (ready[0] != pl.grid || ready[1] != pl.block / 64 || ready[2] != f.queue_shift) // else the frame before left it ready (reduce_samples_kernel)
+            hipLaunchKernelGGL(trt::start_queue_kernel, dim3(1), dim3(64), 0, stream, f.queue, pl.grid, pl.block / 64, f.queue_shift);
+        ready[0] = 0; // the render kernel uses it up
         HIP_TRY(hipEventRecord(ctx->ev_start[slot], stream));
         const bool patches = ctx->grids.path_enabled && ctx->grids.patch_m > 0; // a family per patch of a sphere: its own instantiations
         if (ctx->ior_count)
@@ -324,7 +327,8 @@ static int render_device_on(trt_context *ctx, const Camera *camera, const trt_ro
         { // TRT.c:1063-1065: the mean over each pixel's samples, in sample order
             const long values = pixels * 3;
             hipLaunchKernelGGL(trt::reduce_samples_kernel, dim3((unsigned)((values + TRT_REDUCE_BLOCK - 1) / TRT_REDUCE_BLOCK)), dim3(TRT_REDUCE_BLOCK), 0, stream,
-                               (const double *)scratch.ptr, (double *)d_pixels, values, rays_per_pixel, f.inv_spp);
+                               (const double *)scratch.ptr, (double *)d_pixels, values, rays_per_pixel, f.inv_spp, f.queue, pl.grid, pl.block / 64, f.queue_shift);
+            ready[0] = pl.grid, ready[1] = pl.block / 64, ready[2] = f.queue_shift;
         }
 #endif
         HIP_TRY(hipEventRecord(ctx->ev_stop[slot], stream));
